@@ -1,0 +1,114 @@
+/*
+ * mi_fp8.h -- C ABI of libmi_fp8.so: the MI355X (gfx950) FP8 Linear hot path.
+ *
+ * This is the drop-in boundary of the build.  The reference
+ * (xuanvinh1997/llm-fp8) has no FFI of its own: its FP8 arithmetic is reached
+ * through Python calls into transformer_engine.pytorch modules
+ *   te_llama.py:45-63,76-80      MultiheadAttention / LayerNormMLP under fp8_autocast
+ *   te_llama_hybrid.py:39,75,78  single HYBRID recipe
+ *   te_llama_mxfp8.py:28-29,86,93  MXFP8BlockScaling recipe
+ *   accelerate utils/transformer_engine.py:52-59  nn.Linear -> te.Linear
+ * Each entry point below names the TE-internal kernel
+ * it replaces on that path.  INTEGRATION.md shows the ctypes stub that binds
+ * them (llm_fp8_amd/_lib.py is that stub).
+ *
+ * Conventions
+ *   - plain C, device pointers are `void*` / `float*` into HBM owned by the caller
+ *     (PyTorch caching allocator); the library allocates nothing persistent.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no
+ *     internal synchronisation, no global mutable state besides the thread-local
+ *     error string.
+ *   - return 0 on success, <0 on error: -1 invalid argument, -2 unsupported shape,
+ *     -3 HIP runtime error.  mi_last_error() gives the message (thread-local).
+ *   - matrices are row-major; `fmt`: 0 = OCP E4M3FN, 1 = OCP E5M2.
+ *   - all GEMMs are "TN": D[M,N] = A[M,K] . B[N,K]^T with K contiguous in both
+ *     operands; dgrad / wgrad use the transposed fp8 copies the cast kernels emit.
+ */
+#ifndef MI_FP8_H
+#define MI_FP8_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_FMT_E4M3 0
+#define MI_FMT_E5M2 1
+
+#define MI_OK 0
+#define MI_ERR_ARG (-1)
+#define MI_ERR_SHAPE (-2)
+#define MI_ERR_HIP (-3)
+
+#define MI_AMAX_ALGO_MAX 0
+#define MI_AMAX_ALGO_MOST_RECENT 1
+
+/* ABI version, bumped on any signature change. */
+int mi_abi_version(void);
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* mi_last_error(void);
+/* 1 if the current HIP device is gfx950 (MI355X), else 0; <0 on HIP error. */
+int mi_device_supported(void);
+
+/*
+ * K1/K2  cast (+transpose) + amax, delayed scaling  [replaces TE quantize / cast_transpose].
+ *   y[r*ld_y + c]   = sat_cast_fmt(float(x[r*cols+c]) * *scale)          (RNE, NaN -> 0x7F)
+ *   yT[c*ld_yT + r] = same byte                                           (if yT != NULL)
+ *   *amax           = max(*amax, max|x|)   atomically (fmaxf semantics: NaN ignored)
+ * x: bf16 [rows, cols] contiguous.  rows, cols multiples of 8.  ld_y >= cols, ld_yT >= rows.
+ * y may be NULL when only the transposed copy is wanted.  amax may be NULL.
+ */
+int mi_cast_amax(const void* x_bf16, void* y_fp8, void* yT_fp8, const float* scale, float* amax,
+                 int64_t rows, int64_t cols, int64_t ld_y, int64_t ld_yT, int fmt, void* stream);
+
+/*
+ * K3  amax-history roll + scale update for S slots in ONE launch
+ *     [replaces TE fused_amax_and_scale_update_after_reduction].
+ *   amax = max_h hist[h][s] (algo MAX) | hist[0][s] (MOST_RECENT)
+ *   hist = roll(hist, -1, dim 0); hist[0][s] = 0
+ *   sf = (fp8_max[s] / amax) / 2^margin ; keep old scale if !(amax > 0) or !isfinite(amax);
+ *   sf = FLT_MAX if isinf(sf) ; scale[s] = sf ; scale_inv[s] = 1 / sf
+ * amax_history: [H, S] fp32 row-major.  H <= 4096.
+ */
+int mi_scale_update(float* amax_history, float* scale, float* scale_inv, const float* fp8_max,
+                    int H, int S, int margin, int algo, void* stream);
+
+/*
+ * K4/K5/K6  FP8 x FP8 -> bf16 GEMM on gfx950 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, unit scales)
+ *           [replaces TE's cuBLASLt FP8 GEMM: fprop, dgrad, wgrad].
+ *   D[m*ldd + n] = bf16( (sum_k A[m*lda+k] * B[n*ldb+k]) * (*sa_inv * *sb_inv) + bias[n] )
+ * A: fp8 [M,K] fmt_a, B: fp8 [N,K] fmt_b, D: bf16 [M,N] (out_dtype 0) or fp32 (out_dtype 1).
+ * bias: bf16 [N] or NULL.  M, N multiples of 16 (8 for the generic path), K multiple of 16.
+ * algo: 0 = auto, 1 = generic 64x64 tile, 2 = 256x256 two-phase, 3 = 256x256 eight-phase ping-pong
+ * (2/3 need M,N % 256 == 0 and K % 128 == 0; auto falls back to 1 otherwise).
+ */
+int mi_gemm_fp8(const void* A, const void* B, void* D, const float* sa_inv, const float* sb_inv,
+                const void* bias_bf16, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                int64_t ldd, int fmt_a, int fmt_b, int out_dtype, int algo, void* stream);
+
+/*
+ * K7  MXFP8 block quantise  [replaces TE's MXFP8 quantize, row-wise and column-wise].
+ *   Row-wise: one E8M0 scale per 32 consecutive elements of a row:
+ *     e = roundup_e8m0(amax_blk * (1/fp8_max)); y = sat_cast(x * 2^(127-e))
+ *     y_row [rows, cols] fp8, s_row [rows, cols/32] u8.
+ *   Column-wise (blocks of 32 along rows), emitted TRANSPOSED so it is a TN GEMM operand:
+ *     y_colT [cols, rows] fp8, s_colT [cols, rows/32] u8.
+ * Either pair may be NULL.  rows, cols multiples of 32.
+ */
+int mi_mxfp8_quantize(const void* x_bf16, void* y_row, void* s_row, void* y_colT, void* s_colT,
+                      int64_t rows, int64_t cols, int fmt, void* stream);
+
+/*
+ * K8  block-scaled MXFP8 GEMM (v_mfma_scale_f32_16x16x128_f8f6f4 with per-32 E8M0 scales)
+ *   D[m,n] = bf16( sum_blk 2^(sa[m,blk]+sb[n,blk]-254) * sum_{k in blk} A[m,k] B[n,k] + bias[n] )
+ * A [M,K] fp8 + SA [M,K/32] u8; B [N,K] fp8 + SB [N,K/32] u8; K multiple of 128.
+ */
+int mi_gemm_mxfp8(const void* A, const void* SA, const void* B, const void* SB, void* D,
+                  const void* bias_bf16, int64_t M, int64_t N, int64_t K, int fmt_a, int fmt_b,
+                  int out_dtype, int algo, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_FP8_H */

@@ -1,0 +1,60 @@
+"""ctypes binding of libmi_fp8.so (include/mi_fp8.h).  There is NO fallback: if the HIP library is
+missing or a call fails, this module raises."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi_fp8.so")
+
+MI_FMT_E4M3 = 0
+MI_FMT_E5M2 = 1
+ABI_VERSION = 1
+
+_c_i64 = ctypes.c_int64
+_c_int = ctypes.c_int
+_p = ctypes.c_void_p
+
+# name -> argtypes (all return int unless noted); mirrors include/mi_fp8.h exactly
+SIGNATURES = {
+    "mi_abi_version": [],
+    "mi_last_error": [],
+    "mi_device_supported": [],
+    "mi_cast_amax": [_p, _p, _p, _p, _p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _p],
+    "mi_scale_update": [_p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _p],
+    "mi_gemm_fp8": [_p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64,
+                    _c_int, _c_int, _c_int, _c_int, _p],
+    "mi_mxfp8_quantize": [_p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],
+    "mi_gemm_mxfp8": [_p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_int, _p],
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the library once; raise ImportError loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C llm_fp8_amd/csrc`. "
+            "llm_fp8_amd has no CPU/PyTorch fallback for the FP8 path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_char_p if name == "mi_last_error" else _c_int
+    v = lib.mi_abi_version()
+    if v != ABI_VERSION:
+        raise ImportError(f"libmi_fp8.so ABI version {v} != expected {ABI_VERSION}; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().mi_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libmi_fp8 {what} failed (rc={rc}): {msg}")

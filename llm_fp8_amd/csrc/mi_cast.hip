@@ -1,0 +1,137 @@
+// K1/K2: bf16 -> FP8 cast (+ transposed copy) + per-tensor amax, delayed scaling.
+//
+// HBM-bound: 2 B read + 1 B (K1) or 2 B (K2) written per element.  One workgroup owns a
+// 128x128 element tile (4 waves as 2x2, one 64x64 sub-tile per wave, one 8x8 block per lane).
+//  - loads : 8 x 16 B per lane; the 8 lanes that share a row cover one full 128-B line.
+//  - amax  : fmaxf in registers -> wave shuffle (DPP) -> LDS across the 4 waves -> ONE
+//            atomicMax per workgroup on the float's bit pattern (non-negative floats order
+//            like unsigned ints).
+//  - y     : 8 B per lane per row (64-B runs per wave, 128-B lines per workgroup).
+//  - yT    : the lane's 8x8 byte block is transposed in registers with v_perm_b32 and stored
+//            8 B per column, 64-B runs per wave and 128-B lines per workgroup.
+// Replaces TE's cast / cast_transpose kernels on the reference path
+// (te_llama.py:76-80 -> te.Linear forward/backward).
+#include "mi_common.h"
+
+namespace mi {
+
+// v_perm_b32: result byte i = byte sel[i] of the 8-byte pool {lo = bytes 0..3, hi = bytes 4..7}
+__device__ __forceinline__ u32 bperm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+
+// 4x4 byte transpose: in r[i] = row i (byte j = col j) -> out c[j] = col j (byte i = row i)
+__device__ __forceinline__ void transpose4x4(u32 r0, u32 r1, u32 r2, u32 r3, u32& c0, u32& c1, u32& c2,
+                                             u32& c3) {
+  u32 t01l = bperm(r1, r0, 0x05010400u);  // [r0b0, r1b0, r0b1, r1b1]
+  u32 t01h = bperm(r1, r0, 0x07030602u);  // [r0b2, r1b2, r0b3, r1b3]
+  u32 t23l = bperm(r3, r2, 0x05010400u);
+  u32 t23h = bperm(r3, r2, 0x07030602u);
+  c0 = bperm(t23l, t01l, 0x05040100u);  // [t01l.b0, t01l.b1, t23l.b0, t23l.b1]
+  c1 = bperm(t23l, t01l, 0x07060302u);
+  c2 = bperm(t23h, t01h, 0x05040100u);
+  c3 = bperm(t23h, t01h, 0x07060302u);
+}
+
+template <int FMT, bool WRITE_Y, bool WRITE_T>
+__global__ __launch_bounds__(256) void cast_amax_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ y,
+                                                        uint8_t* __restrict__ yT, const float* __restrict__ scale_p,
+                                                        float* amax_out, int rows, int cols, int64_t ld_y,
+                                                        int64_t ld_yT, int tiles_c) {
+  __shared__ float s_amax[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile_r = blockIdx.x / tiles_c, tile_c = blockIdx.x % tiles_c;
+  const int r0 = tile_r * 128 + (wave >> 1) * 64 + (lane >> 3) * 8;
+  const int c0 = tile_c * 128 + (wave & 1) * 64 + (lane & 7) * 8;
+  const float scale = *scale_p;
+  float amax = 0.0f;
+  const bool active = (r0 < rows) && (c0 < cols);  // dims are multiples of 8: blocks are all-in or all-out
+  if (active) {
+    v4i raw[8];
+    const uint16_t* src = x + (int64_t)r0 * cols + c0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) raw[i] = *reinterpret_cast<const v4i*>(src + (int64_t)i * cols);
+    u32 lo[8], hi[8];  // fp8 bytes of row i: lo = cols 0..3, hi = cols 4..7
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        u32 w = (u32)raw[i][j];
+        f[2 * j] = __uint_as_float(w << 16);
+        f[2 * j + 1] = __uint_as_float(w & 0xFFFF0000u);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(f[j]));
+      lo[i] = cvt4_fp8<FMT>(f[0] * scale, f[1] * scale, f[2] * scale, f[3] * scale);
+      hi[i] = cvt4_fp8<FMT>(f[4] * scale, f[5] * scale, f[6] * scale, f[7] * scale);
+    }
+    if (WRITE_Y) {
+      uint8_t* dst = y + (int64_t)r0 * ld_y + c0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<uint2*>(dst + (int64_t)i * ld_y) = make_uint2(lo[i], hi[i]);
+    }
+    if (WRITE_T) {
+      u32 a[4], b[4], c[4], d[4];
+      transpose4x4(lo[0], lo[1], lo[2], lo[3], a[0], a[1], a[2], a[3]);  // cols 0..3, rows 0..3
+      transpose4x4(lo[4], lo[5], lo[6], lo[7], b[0], b[1], b[2], b[3]);  // cols 0..3, rows 4..7
+      transpose4x4(hi[0], hi[1], hi[2], hi[3], c[0], c[1], c[2], c[3]);  // cols 4..7, rows 0..3
+      transpose4x4(hi[4], hi[5], hi[6], hi[7], d[0], d[1], d[2], d[3]);  // cols 4..7, rows 4..7
+      uint8_t* dst = yT + (int64_t)c0 * ld_yT + r0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<uint2*>(dst + (int64_t)j * ld_yT) = make_uint2(a[j], b[j]);
+        *reinterpret_cast<uint2*>(dst + (int64_t)(j + 4) * ld_yT) = make_uint2(c[j], d[j]);
+      }
+    }
+  }
+  if (amax_out != nullptr) {
+    amax = wave_max(amax);
+    if (lane == 0) s_amax[wave] = amax;
+    __syncthreads();
+    if (tid == 0) {
+      float m = fmaxf(fmaxf(s_amax[0], s_amax[1]), fmaxf(s_amax[2], s_amax[3]));
+      if (m > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(amax_out), __float_as_uint(m));
+    }
+  }
+}
+
+template <int FMT>
+static int launch_cast(const void* x, void* y, void* yT, const float* scale, float* amax, int64_t rows,
+                       int64_t cols, int64_t ld_y, int64_t ld_yT, hipStream_t st) {
+  const int tiles_r = (int)((rows + 127) / 128), tiles_c = (int)((cols + 127) / 128);
+  dim3 grid((unsigned)(tiles_r * tiles_c)), block(256);
+  const uint16_t* xp = (const uint16_t*)x;
+  uint8_t *yp = (uint8_t*)y, *tp = (uint8_t*)yT;
+  if (y && yT)
+    hipLaunchKernelGGL((cast_amax_kernel<FMT, true, true>), grid, block, 0, st, xp, yp, tp, scale, amax, (int)rows,
+                       (int)cols, ld_y, ld_yT, tiles_c);
+  else if (y)
+    hipLaunchKernelGGL((cast_amax_kernel<FMT, true, false>), grid, block, 0, st, xp, yp, tp, scale, amax, (int)rows,
+                       (int)cols, ld_y, ld_yT, tiles_c);
+  else
+    hipLaunchKernelGGL((cast_amax_kernel<FMT, false, true>), grid, block, 0, st, xp, yp, tp, scale, amax, (int)rows,
+                       (int)cols, ld_y, ld_yT, tiles_c);
+  MI_CHECK_LAUNCH("mi_cast_amax launch");
+  return MI_OK;
+}
+
+}  // namespace mi
+
+extern "C" int mi_cast_amax(const void* x_bf16, void* y_fp8, void* yT_fp8, const float* scale, float* amax,
+                            int64_t rows, int64_t cols, int64_t ld_y, int64_t ld_yT, int fmt, void* stream) {
+  MI_CHECK_ARG(x_bf16 && scale, "mi_cast_amax: x and scale must be non-null");
+  MI_CHECK_ARG(y_fp8 || yT_fp8, "mi_cast_amax: at least one of y, yT must be non-null");
+  MI_CHECK_ARG(rows >= 0 && cols >= 0, "mi_cast_amax: negative shape");
+  MI_CHECK_ARG(rows % 8 == 0 && cols % 8 == 0, "mi_cast_amax: rows (%lld) and cols (%lld) must be multiples of 8",
+               (long long)rows, (long long)cols);
+  MI_CHECK_ARG(rows < (1LL << 31) && cols < (1LL << 31) && ((rows + 127) / 128) * ((cols + 127) / 128) < (1LL << 31),
+               "mi_cast_amax: shape too large");
+  MI_CHECK_ARG(!y_fp8 || (ld_y >= cols && ld_y % 8 == 0), "mi_cast_amax: ld_y must be >= cols and a multiple of 8");
+  MI_CHECK_ARG(!yT_fp8 || (ld_yT >= rows && ld_yT % 8 == 0), "mi_cast_amax: ld_yT must be >= rows and a multiple of 8");
+  MI_CHECK_ARG(((uintptr_t)x_bf16 % 16) == 0 && ((uintptr_t)y_fp8 % 8) == 0 && ((uintptr_t)yT_fp8 % 8) == 0,
+               "mi_cast_amax: x must be 16-byte aligned, y/yT 8-byte aligned");
+  MI_CHECK_ARG(fmt == MI_FMT_E4M3 || fmt == MI_FMT_E5M2, "mi_cast_amax: bad fmt %d", fmt);
+  if (rows == 0 || cols == 0) return MI_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (fmt == MI_FMT_E4M3) return mi::launch_cast<MI_FMT_E4M3>(x_bf16, y_fp8, yT_fp8, scale, amax, rows, cols, ld_y, ld_yT, st);
+  return mi::launch_cast<MI_FMT_E5M2>(x_bf16, y_fp8, yT_fp8, scale, amax, rows, cols, ld_y, ld_yT, st);
+}

@@ -1,0 +1,340 @@
+// K4/K5/K6 (+K8): FP8 x FP8 -> bf16 "TN" GEMM on gfx950 MFMA.
+//
+//   D[M,N] = (A[M,K] . B[N,K]^T) * alpha (+ bias),  A/B fp8 (E4M3 or E5M2 each), fp32 accumulate.
+//
+// Instruction: v_mfma_scale_f32_16x16x128_f8f6f4 -- the only FP8 form that reaches the ~5 PFLOP/s
+// dense peak (the MI300-era 16x16x32_fp8_fp8 runs at the bf16 rate).  Per-tensor (delayed) scaling
+// passes unit E8M0 scales (0x7F) and applies alpha = sa_inv*sb_inv in the epilogue; MXFP8 passes the
+// real per-32 E8M0 block scales.  Operand lane map used here (K-permutation-invariant, so only the
+// pairing of A and B bytes matters): lane l holds row (l & 15), the 32 consecutive K-bytes of
+// k-block (l >> 4) of the 128-deep step, as two 16-B LDS reads.  Result: we issue mfma(B, A) so
+// that a lane holds 4 consecutive n for one m (row = lane & 15 -> m, (lane >> 4)*4 + reg -> n).
+//
+// Kernels
+//   gemm_generic   64x64 tile, register-staged, fully predicated: any M,N (mult. of 8), K mult. of 16.
+//   gemm_256_2ph   256x256x128 tile, 8 waves (2M x 4N, 128x64 per wave), direct-to-LDS staging
+//                  (global_load_lds_dwordx4), 2 LDS buffers, one barrier per K-step.
+// LDS image (both fast kernels): per operand tile 256 rows x 128 B, cut into 1-KiB pieces of
+// 8 rows x 128 B -- exactly what one wave-wide global_load_lds_dwordx4 writes, and each row a full
+// 128-B line of the source.  The 16-B chunk c of row r (r = row within its 16-row MFMA group)
+// sits at chunk position c ^ f(r), f(r) = ((r>>1)&1) | (((r>>3)&1)<<2): with it the two
+// ds_read_b128 of a fragment hit 16 distinct 16-B bank slots in every 16-lane service group.
+// The swizzle is applied on the global SOURCE address (LDS-DMA writes lane-linear) and again
+// on the read address.
+//
+// Replaces the cuBLASLt FP8 GEMMs behind te.Linear / LayerNormLinear / LayerNormMLP on the
+// reference path (te_llama.py:45-63,76-80; Appendix B shapes).
+#include "mi_common.h"
+
+namespace mi {
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+constexpr int kUnitScale = 0x7F7F7F7F;
+
+template <int FA, int FB>
+__device__ __forceinline__ v4f mfma_ba(const v8i& a, const v8i& b, v4f acc, int sa, int sb) {
+  // first operand = B fragment (rows -> n), second = A fragment (cols -> m): acc[j] = D[m = lane&15][n = 4*(lane>>4)+j]
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b, a, acc, FB, FA, 0, sb, 0, sa);
+}
+
+__device__ __forceinline__ int swz_f(int r16) { return ((r16 >> 1) & 1) | (((r16 >> 3) & 1) << 2); }
+
+// ------------------------------------------------------------------------------------------------
+// Epilogue shared by the kernels: lane holds acc[j] for (m, n0 + j), j = 0..3.
+template <int OUT>
+__device__ __forceinline__ void store4(void* D, int64_t ldd, int64_t m, int64_t n0, v4f v) {
+  if (OUT == 0) {
+    uint2 p = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(D) + m * ldd + n0) = p;
+  } else {
+    *reinterpret_cast<v4f*>(reinterpret_cast<float*>(D) + m * ldd + n0) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic path.  64x64 tile, 4 waves (2x2), each wave 32x32 = 2x2 MFMA tiles, BK = 128.
+// LDS: A[64][128] + B[64][128] bytes, chunk position = chunk ^ (row & 7).
+template <int FA, int FB, int OUT, bool MX>
+__global__ __launch_bounds__(256) void gemm_generic(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
+                                                    void* __restrict__ D, const float* __restrict__ sa_inv,
+                                                    const float* __restrict__ sb_inv,
+                                                    const uint8_t* __restrict__ SA, const uint8_t* __restrict__ SB,
+                                                    const uint16_t* __restrict__ bias, int M, int N, int K,
+                                                    int64_t lda, int64_t ldb, int64_t ldd) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[2 * 64 * 128];
+  uint8_t* lA = lds;
+  uint8_t* lB = lds + 64 * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int fr = lane & 15, fq = lane >> 4;
+  v4f acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+  const int kb = K / 32;  // scale blocks per row (MX)
+  for (int k0 = 0; k0 < K; k0 += 128) {
+    // stage: 512 chunks per operand, 2 per thread
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int ch = tid + i * 256;
+      int row = ch >> 3, c = ch & 7;
+      v4i va = {0, 0, 0, 0}, vb = {0, 0, 0, 0};
+      if (m0 + row < M && k0 + c * 16 < K) va = *reinterpret_cast<const v4i*>(A + (int64_t)(m0 + row) * lda + k0 + c * 16);
+      if (n0 + row < N && k0 + c * 16 < K) vb = *reinterpret_cast<const v4i*>(B + (int64_t)(n0 + row) * ldb + k0 + c * 16);
+      *reinterpret_cast<v4i*>(lA + row * 128 + ((c ^ (row & 7)) * 16)) = va;
+      *reinterpret_cast<v4i*>(lB + row * 128 + ((c ^ (row & 7)) * 16)) = vb;
+    }
+    __syncthreads();
+    v8i af[2], bf[2];
+    int sa[2] = {kUnitScale, kUnitScale}, sb[2] = {kUnitScale, kUnitScale};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      int ra = wr * 32 + t * 16 + fr, rb = wc * 32 + t * 16 + fr;
+      v4i a0 = *reinterpret_cast<const v4i*>(lA + ra * 128 + (((2 * fq) ^ (ra & 7)) * 16));
+      v4i a1 = *reinterpret_cast<const v4i*>(lA + ra * 128 + (((2 * fq + 1) ^ (ra & 7)) * 16));
+      v4i b0 = *reinterpret_cast<const v4i*>(lB + rb * 128 + (((2 * fq) ^ (rb & 7)) * 16));
+      v4i b1 = *reinterpret_cast<const v4i*>(lB + rb * 128 + (((2 * fq + 1) ^ (rb & 7)) * 16));
+      af[t] = (v8i){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      bf[t] = (v8i){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      if (MX) {
+        int blk = k0 / 32 + fq;
+        // out-of-range rows / k-blocks multiply zero data: any finite scale works, use 2^0
+        sa[t] = (m0 + ra < M && blk < kb) ? (int)SA[(int64_t)(m0 + ra) * kb + blk] : 0x7F;
+        sb[t] = (n0 + rb < N && blk < kb) ? (int)SB[(int64_t)(n0 + rb) * kb + blk] : 0x7F;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = mfma_ba<FA, FB>(af[i], bf[j], acc[i][j], sa[i], sb[j]);
+    __syncthreads();
+  }
+  float alpha = 1.0f;
+  if (!MX) alpha = (*sa_inv) * (*sb_inv);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int m = m0 + wr * 32 + i * 16 + fr;
+      int n = n0 + wc * 32 + j * 16 + fq * 4;
+      if (m < M && n < N) {  // N is a multiple of 4 (checked on the host): the 4-wide group is all-in or all-out
+        v4f v = acc[i][j] * alpha;
+        if (bias) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bf16_bits_to_float(bias[n + e]);
+        }
+        store4<OUT>(D, ldd, m, n, v);
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast path geometry
+constexpr int BM = 256, BN = 256, BK = 128;
+constexpr int kTileBytes = BM * BK;          // 32 KiB per operand tile
+constexpr int kBufBytes = 2 * kTileBytes;    // A + B
+constexpr int kLdsBytes = 2 * kBufBytes;     // double buffer = 128 KiB
+
+// XCD-aware, L2-friendly workgroup -> tile map.  Workgroups are dealt round-robin over the 8
+// XCDs; give every XCD a contiguous run of the (grouped) tile order so the tiles resident on one
+// L2 share A/B panels.  Bijective for any grid size.  Speed only -- never correctness.
+__device__ __forceinline__ void tile_of_block(int bid, int nwg, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  constexpr int GM = 4;  // super-rows of 4 tile-rows, column-major inside
+  int group = id / (GM * tiles_n);
+  int first_m = group * GM;
+  int gsz = min(tiles_m - first_m, GM);
+  int in_g = id - group * GM * tiles_n;
+  tm = first_m + in_g % gsz;
+  tn = in_g / gsz;
+}
+
+// Stage one operand tile (256 rows x 128 B) of K-step kt into LDS at `lds_tile`.
+// wave w issues 4 x global_load_lds_dwordx4, pieces s = 4w .. 4w+3 (8 rows each).
+__device__ __forceinline__ void stage_tile(const uint8_t* __restrict__ g_tile_row0, int64_t ld, int k_byte,
+                                           uint8_t* lds_tile, int wave, int lane) {
+  const int lr = lane >> 3, lc = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = wave * 4 + i;
+    const int r16 = ((i & 1) << 3) | lr;          // row within the 16-row MFMA group
+    const int src_chunk = lc ^ swz_f(r16);
+    const uint8_t* src = g_tile_row0 + (int64_t)(piece * 8 + lr) * ld + k_byte + src_chunk * 16;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + piece * 1024), 16, 0, 0);
+  }
+}
+
+// Read the fragment of 16-row group `g` (rows 16g..16g+15 of the tile) for this lane.
+__device__ __forceinline__ v8i read_frag(const uint8_t* lds_tile, int g, int lane) {
+  const int r = lane & 15, q = lane >> 4;
+  const int f = swz_f(r);
+  const uint8_t* base = lds_tile + g * 2048 + (r >> 3) * 1024 + (r & 7) * 128;
+  v4i lo = *reinterpret_cast<const v4i*>(base + (((2 * q) ^ f) << 4));
+  v4i hi = *reinterpret_cast<const v4i*>(base + (((2 * q + 1) ^ f) << 4));
+  return (v8i){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int FA, int FB, int OUT>
+__global__ __launch_bounds__(512, 2) void gemm_256_2ph(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
+                                                       void* __restrict__ D, const float* __restrict__ sa_inv,
+                                                       const float* __restrict__ sb_inv,
+                                                       const uint16_t* __restrict__ bias, int M, int N, int K,
+                                                       int64_t lda, int64_t ldb, int64_t ldd, int tiles_m,
+                                                       int tiles_n) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;  // 2 (M) x 4 (N)
+  int tm, tn;
+  tile_of_block(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
+  const uint8_t* gA = A + (int64_t)tm * BM * lda;
+  const uint8_t* gB = B + (int64_t)tn * BN * ldb;
+  v4f acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+  const int nk = K / BK;
+  stage_tile(gA, lda, 0, lds, wave, lane);
+  stage_tile(gB, ldb, 0, lds + kTileBytes, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    uint8_t* cur = lds + (kt & 1) * kBufBytes;
+    uint8_t* nxt = lds + ((kt + 1) & 1) * kBufBytes;
+    if (kt + 1 < nk) {
+      stage_tile(gA, lda, (kt + 1) * BK, nxt, wave, lane);
+      stage_tile(gB, ldb, (kt + 1) * BK, nxt + kTileBytes, wave, lane);
+    }
+    v8i bf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bf[j] = read_frag(cur + kTileBytes, wc * 4 + j, lane);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v8i af = read_frag(cur, wr * 8 + i, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = mfma_ba<FA, FB>(af, bf[j], acc[i][j], kUnitScale, kUnitScale);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  const float alpha = (*sa_inv) * (*sb_inv);
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t n = (int64_t)tn * BN + wc * 64 + j * 16 + fq * 4;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[e] = bf16_bits_to_float(bias[n + e]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int64_t m = (int64_t)tm * BM + wr * 128 + i * 16 + fr;
+      v4f v = acc[i][j] * alpha;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += bv[e];
+      store4<OUT>(D, ldd, m, n, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int FA, int FB, int OUT>
+static int launch_fmt(const void* A, const void* B, void* D, const float* sa_inv, const float* sb_inv,
+                      const void* SA, const void* SB, const void* bias, int64_t M, int64_t N, int64_t K,
+                      int64_t lda, int64_t ldb, int64_t ldd, int algo, bool mx, hipStream_t st) {
+  const uint8_t *a = (const uint8_t*)A, *b = (const uint8_t*)B;
+  const uint16_t* bp = (const uint16_t*)bias;
+  if (algo == 2 && !mx) {
+    int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
+    hipLaunchKernelGGL((gemm_256_2ph<FA, FB, OUT>), dim3(tiles_m * tiles_n), dim3(512), 0, st, a, b, D, sa_inv, sb_inv,
+                       bp, (int)M, (int)N, (int)K, lda, ldb, ldd, tiles_m, tiles_n);
+  } else {
+    dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
+    if (mx)
+      hipLaunchKernelGGL((gemm_generic<FA, FB, OUT, true>), grid, dim3(256), 0, st, a, b, D, sa_inv, sb_inv,
+                         (const uint8_t*)SA, (const uint8_t*)SB, bp, (int)M, (int)N, (int)K, lda, ldb, ldd);
+    else
+      hipLaunchKernelGGL((gemm_generic<FA, FB, OUT, false>), grid, dim3(256), 0, st, a, b, D, sa_inv, sb_inv,
+                         (const uint8_t*)SA, (const uint8_t*)SB, bp, (int)M, (int)N, (int)K, lda, ldb, ldd);
+  }
+  MI_CHECK_LAUNCH("mi_gemm launch");
+  return MI_OK;
+}
+
+static int dispatch(const void* A, const void* B, void* D, const float* sa_inv, const float* sb_inv, const void* SA,
+                    const void* SB, const void* bias, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                    int64_t ldd, int fa, int fb, int out, int algo, bool mx, hipStream_t st) {
+#define MI_CASE(FA_, FB_, OUT_)                                                                               \
+  if (fa == FA_ && fb == FB_ && out == OUT_)                                                                  \
+    return launch_fmt<FA_, FB_, OUT_>(A, B, D, sa_inv, sb_inv, SA, SB, bias, M, N, K, lda, ldb, ldd, algo, mx, st);
+  MI_CASE(0, 0, 0) MI_CASE(0, 1, 0) MI_CASE(1, 0, 0) MI_CASE(1, 1, 0)
+  MI_CASE(0, 0, 1) MI_CASE(0, 1, 1) MI_CASE(1, 0, 1) MI_CASE(1, 1, 1)
+#undef MI_CASE
+  set_error("mi_gemm: unsupported format/out combination (%d,%d,%d)", fa, fb, out);
+  return MI_ERR_ARG;
+}
+
+static int check_common(const char* who, const void* A, const void* B, void* D, int64_t M, int64_t N, int64_t K,
+                        int64_t lda, int64_t ldb, int64_t ldd, int fa, int fb, int out) {
+  MI_CHECK_ARG(A && B && D, "%s: null operand", who);
+  MI_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "%s: negative shape", who);
+  MI_CHECK_ARG(M % 8 == 0 && N % 8 == 0 && K % 16 == 0, "%s: M,N must be multiples of 8 and K of 16 (got %lld,%lld,%lld)",
+               who, (long long)M, (long long)N, (long long)K);
+  MI_CHECK_ARG(M < (1LL << 31) && N < (1LL << 31) && K < (1LL << 31), "%s: shape too large", who);
+  MI_CHECK_ARG(lda >= K && ldb >= K && ldd >= N && lda % 16 == 0 && ldb % 16 == 0 && ldd % 4 == 0,
+               "%s: bad leading dimensions", who);
+  MI_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)D % 16) == 0,
+               "%s: operands must be 16-byte aligned", who);
+  MI_CHECK_ARG((fa == 0 || fa == 1) && (fb == 0 || fb == 1) && (out == 0 || out == 1), "%s: bad fmt/out_dtype", who);
+  return MI_OK;
+}
+
+static int pick_algo(int algo, int64_t M, int64_t N, int64_t K, const char* who) {
+  const bool fast_ok = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && M > 0 && N > 0 && K > 0;
+  if (algo == 0) return fast_ok ? 2 : 1;
+  if (algo == 1) return 1;
+  if (algo == 2 || algo == 3) {
+    if (!fast_ok) {
+      set_error("%s: algo %d needs M,N %% 256 == 0 and K %% 128 == 0", who, algo);
+      return MI_ERR_SHAPE;
+    }
+    return 2;
+  }
+  set_error("%s: unknown algo %d", who, algo);
+  return MI_ERR_ARG;
+}
+
+}  // namespace mi
+
+extern "C" int mi_gemm_fp8(const void* A, const void* B, void* D, const float* sa_inv, const float* sb_inv,
+                           const void* bias_bf16, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
+                           int64_t ldd, int fmt_a, int fmt_b, int out_dtype, int algo, void* stream) {
+  int rc = mi::check_common("mi_gemm_fp8", A, B, D, M, N, K, lda, ldb, ldd, fmt_a, fmt_b, out_dtype);
+  if (rc != MI_OK) return rc;
+  MI_CHECK_ARG(sa_inv && sb_inv, "mi_gemm_fp8: null scale pointer");
+  if (M == 0 || N == 0) return MI_OK;
+  int a = mi::pick_algo(algo, M, N, K, "mi_gemm_fp8");
+  if (a < 0) return a;
+  return mi::dispatch(A, B, D, sa_inv, sb_inv, nullptr, nullptr, bias_bf16, M, N, K, lda, ldb, ldd, fmt_a, fmt_b,
+                      out_dtype, a, false, (hipStream_t)stream);
+}
+
+extern "C" int mi_gemm_mxfp8(const void* A, const void* SA, const void* B, const void* SB, void* D,
+                             const void* bias_bf16, int64_t M, int64_t N, int64_t K, int fmt_a, int fmt_b,
+                             int out_dtype, int algo, void* stream) {
+  int rc = mi::check_common("mi_gemm_mxfp8", A, B, D, M, N, K, K, K, N, fmt_a, fmt_b, out_dtype);
+  if (rc != MI_OK) return rc;
+  MI_CHECK_ARG(SA && SB, "mi_gemm_mxfp8: null scale pointer");
+  MI_CHECK_ARG(K % 32 == 0, "mi_gemm_mxfp8: K must be a multiple of 32");
+  if (M == 0 || N == 0) return MI_OK;
+  (void)algo;
+  return mi::dispatch(A, B, D, nullptr, nullptr, SA, SB, bias_bf16, M, N, K, K, K, N, fmt_a, fmt_b, out_dtype, 1, true,
+                      (hipStream_t)stream);
+}

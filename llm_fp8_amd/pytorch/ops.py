@@ -1,0 +1,126 @@
+"""Thin tensor-level wrappers over the C ABI (include/mi_fp8.h).  Device tensors only: every
+function raises if handed a CPU tensor -- there is no PyTorch/CPU fallback for this path."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from .. import _lib
+
+E4M3, E5M2 = _lib.MI_FMT_E4M3, _lib.MI_FMT_E5M2
+FP8_MAX = {E4M3: 448.0, E5M2: 57344.0}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("llm_fp8_amd ops need device (HIP) tensors; there is no CPU fallback")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def cast_amax(x: torch.Tensor, scale: torch.Tensor, amax: Optional[torch.Tensor], fmt: int,
+              want_y: bool = True, want_t: bool = True,
+              y: Optional[torch.Tensor] = None, yT: Optional[torch.Tensor] = None
+              ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """K1/K2.  x bf16 [R, C] contiguous -> (y u8 [R, C], yT u8 [C, R]); amax (1-elem f32 view) is
+    atomically maxed with max|x|.  `y` / `yT` may be preallocated row-slices of larger buffers
+    (their stride(0) is used as leading dimension)."""
+    _dev(x, scale, amax, y, yT)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.is_contiguous()
+    assert scale.dtype == torch.float32 and (amax is None or amax.dtype == torch.float32)
+    R, C = x.shape
+    if want_y and y is None:
+        y = torch.empty((R, C), dtype=torch.uint8, device=x.device)
+    if want_t and yT is None:
+        yT = torch.empty((C, R), dtype=torch.uint8, device=x.device)
+    if y is not None:
+        assert y.dtype == torch.uint8 and y.shape == (R, C) and y.stride(1) == 1
+    if yT is not None:
+        assert yT.dtype == torch.uint8 and yT.shape == (C, R) and yT.stride(1) == 1
+    lib = _lib.load()
+    rc = lib.mi_cast_amax(x.data_ptr(), _ptr(y), _ptr(yT), scale.data_ptr(), _ptr(amax), R, C,
+                          y.stride(0) if y is not None else C, yT.stride(0) if yT is not None else R,
+                          fmt, _stream())
+    _lib.check(rc, "mi_cast_amax")
+    return y, yT
+
+
+def scale_update(amax_history: torch.Tensor, scale: torch.Tensor, scale_inv: torch.Tensor,
+                 fp8_max: torch.Tensor, margin: int = 0, algo: str = "max") -> None:
+    """K3, in place on [H, S] history and [S] scale / scale_inv."""
+    _dev(amax_history, scale, scale_inv, fp8_max)
+    assert amax_history.dim() == 2 and amax_history.is_contiguous() and amax_history.dtype == torch.float32
+    H, S = amax_history.shape
+    assert scale.numel() == S and scale_inv.numel() == S and fp8_max.numel() == S
+    assert scale.is_contiguous() and scale_inv.is_contiguous() and fp8_max.is_contiguous()
+    rc = _lib.load().mi_scale_update(amax_history.data_ptr(), scale.data_ptr(), scale_inv.data_ptr(),
+                                     fp8_max.data_ptr(), H, S, margin, 0 if algo == "max" else 1, _stream())
+    _lib.check(rc, "mi_scale_update")
+
+
+def gemm_fp8(a8: torch.Tensor, b8: torch.Tensor, sa_inv: torch.Tensor, sb_inv: torch.Tensor,
+             fmt_a: int, fmt_b: int, bias: Optional[torch.Tensor] = None,
+             out: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.bfloat16,
+             algo: int = 0) -> torch.Tensor:
+    """K4-K6.  D[M,N] = (A[M,K] . B[N,K]^T) * sa_inv * sb_inv (+ bias)."""
+    _dev(a8, b8, sa_inv, sb_inv, bias, out)
+    assert a8.dtype == torch.uint8 and b8.dtype == torch.uint8 and a8.dim() == 2 and b8.dim() == 2
+    assert a8.stride(1) == 1 and b8.stride(1) == 1
+    M, K = a8.shape
+    N, K2 = b8.shape
+    assert K == K2, f"contraction mismatch {K} vs {K2}"
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a8.device)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype in (torch.bfloat16, torch.float32)
+    if bias is not None:
+        assert bias.dtype == torch.bfloat16 and bias.numel() == N and bias.is_contiguous()
+    rc = _lib.load().mi_gemm_fp8(a8.data_ptr(), b8.data_ptr(), out.data_ptr(), sa_inv.data_ptr(),
+                                 sb_inv.data_ptr(), _ptr(bias), M, N, K, a8.stride(0), b8.stride(0),
+                                 out.stride(0), fmt_a, fmt_b, 0 if out.dtype == torch.bfloat16 else 1,
+                                 algo, _stream())
+    _lib.check(rc, "mi_gemm_fp8")
+    return out
+
+
+def mxfp8_quantize(x: torch.Tensor, fmt: int = E4M3, rowwise: bool = True, colwise: bool = True):
+    """K7.  Returns (y_row [R,C], s_row [R,C/32], y_colT [C,R], s_colT [C,R/32]) (None where not asked)."""
+    _dev(x)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.is_contiguous()
+    R, C = x.shape
+    y_row = s_row = y_colT = s_colT = None
+    if rowwise:
+        y_row = torch.empty((R, C), dtype=torch.uint8, device=x.device)
+        s_row = torch.empty((R, C // 32), dtype=torch.uint8, device=x.device)
+    if colwise:
+        y_colT = torch.empty((C, R), dtype=torch.uint8, device=x.device)
+        s_colT = torch.empty((C, R // 32), dtype=torch.uint8, device=x.device)
+    rc = _lib.load().mi_mxfp8_quantize(x.data_ptr(), _ptr(y_row), _ptr(s_row), _ptr(y_colT), _ptr(s_colT),
+                                       R, C, fmt, _stream())
+    _lib.check(rc, "mi_mxfp8_quantize")
+    return y_row, s_row, y_colT, s_colT
+
+
+def gemm_mxfp8(a8, sa, b8, sb, fmt_a: int = E4M3, fmt_b: int = E4M3, bias=None, out=None,
+               out_dtype: torch.dtype = torch.bfloat16, algo: int = 0) -> torch.Tensor:
+    """K8.  Block-scaled D[M,N] = sum_blk 2^(sa+sb-254) sum_32 A.B (+bias)."""
+    _dev(a8, sa, b8, sb, bias, out)
+    M, K = a8.shape
+    N, K2 = b8.shape
+    assert K == K2 and a8.is_contiguous() and b8.is_contiguous() and sa.is_contiguous() and sb.is_contiguous()
+    assert sa.shape == (M, K // 32) and sb.shape == (N, K // 32)
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a8.device)
+    assert out.is_contiguous() and out.shape == (M, N)
+    rc = _lib.load().mi_gemm_mxfp8(a8.data_ptr(), sa.data_ptr(), b8.data_ptr(), sb.data_ptr(), out.data_ptr(),
+                                   _ptr(bias), M, N, K, fmt_a, fmt_b,
+                                   0 if out.dtype == torch.bfloat16 else 1, algo, _stream())
+    _lib.check(rc, "mi_gemm_mxfp8")
+    return out

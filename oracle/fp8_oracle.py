@@ -1,0 +1,344 @@
+"""CPU oracle for the FP8 Linear hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module.  Nothing under ``llm_fp8_amd/`` imports it and the
+product path has no CPU fallback.
+
+PARITY UNPINNED.  The arithmetic this file restates lives in a third-party
+dependency of the reference that is absent from ``/root/reference`` and from
+this container: NVIDIA Transformer Engine (``transformer_engine[pytorch]``,
+unpinned in ``install.sh:4``; "Transformer Engine 2.5.0" per
+``paper/conference_101719.tex:236``).  The reference holds no test, golden
+vector or fixture for this path.  What is restated
+here is the published OCP FP8 (E4M3FN / E5M2) and OCP MX (E8M0 block scale)
+formats plus TE's delayed-scaling recipe as summarised in SURVEY.md Appendix A,
+anchored on the reference's call sites:
+
+* recipes        te_llama.py:39-40, te_llama_hybrid.py:39, te_llama_mxfp8.py:28-29
+* module layout  te_llama.py:41-82 (MultiheadAttention + LayerNormMLP)
+* weight layout  te_llama.py:181-239 (replace_params: q|k|v, gate|up order)
+* outer recipe   train_fp8.py:126-165, accelerate utils/transformer_engine.py:118-186
+
+The fp8 encoders are written with integer/bit arithmetic only (numpy) and are
+cross-checked in ``tests/test_oracle.py`` against torch's independent
+``float8_e4m3fn`` / ``float8_e5m2`` casts and hand-derived known answers.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+E4M3 = 0  # OCP E4M3FN: bias 7, max 448, no inf, NaN = S.1111.111
+E5M2 = 1  # OCP E5M2  : bias 15, max 57344, inf/NaN IEEE-like
+
+FP8_MAX = {E4M3: np.float32(448.0), E5M2: np.float32(57344.0)}
+_MBITS = {E4M3: 3, E5M2: 2}
+_BIAS = {E4M3: 7, E5M2: 15}
+FP8_NAN_BYTE = 0x7F  # canonical NaN byte produced by the quantiser for either format
+
+
+# --------------------------------------------------------------------------- bf16 helpers
+def bf16_bits_to_f32(bits: np.ndarray) -> np.ndarray:
+    """uint16 bf16 bit patterns -> float32 (exact)."""
+    return (np.asarray(bits, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """float32 -> bf16 bit patterns, round-to-nearest-even, NaN stays NaN (quiet)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    rounded = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+    nan = np.isnan(x)
+    if np.any(nan):
+        rounded = np.where(nan, ((u >> 16) | 0x40).astype(np.uint16), rounded)
+    return rounded
+
+
+def round_to_bf16(x: np.ndarray) -> np.ndarray:
+    return bf16_bits_to_f32(f32_to_bf16_bits(x))
+
+
+# --------------------------------------------------------------------------- fp8 codec
+def fp8_decode_table(fmt: int) -> np.ndarray:
+    """256-entry float32 table byte -> value (OCP FP8)."""
+    m, bias = _MBITS[fmt], _BIAS[fmt]
+    out = np.zeros(256, dtype=np.float64)
+    for b in range(256):
+        s = -1.0 if b & 0x80 else 1.0
+        e = (b & 0x7F) >> m
+        f = b & ((1 << m) - 1)
+        if fmt == E4M3 and (b & 0x7F) == 0x7F:
+            v = np.nan
+        elif fmt == E5M2 and e == 31:
+            v = np.inf if f == 0 else np.nan
+        elif e == 0:
+            v = f * 2.0 ** (1 - bias - m)
+        else:
+            v = (1 + f / (1 << m)) * 2.0 ** (e - bias)
+        out[b] = s * v
+    return out.astype(np.float32)
+
+
+_DEC = {E4M3: fp8_decode_table(E4M3), E5M2: fp8_decode_table(E5M2)}
+
+
+def fp8_decode(bytes_: np.ndarray, fmt: int) -> np.ndarray:
+    return _DEC[fmt][np.asarray(bytes_, dtype=np.uint8)]
+
+
+def fp8_encode_sat(v: np.ndarray, fmt: int) -> np.ndarray:
+    """float32 -> fp8 byte: saturate to +-max (inf included), then round-to-nearest-even.
+
+    NaN -> 0x7F (sign dropped) for both formats.  -0.0 -> 0x80.  Works on the
+    float32 bit pattern with integer arithmetic only.
+    """
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    m, bias = _MBITS[fmt], _BIAS[fmt]
+    u = v.view(np.uint32).astype(np.int64)
+    sign = ((u >> 31) & 1).astype(np.int64)
+    mag = u & 0x7FFFFFFF
+    isnan = mag > 0x7F800000
+    max_bits = np.int64(np.float32(FP8_MAX[fmt]).view(np.uint32))
+    mag = np.minimum(mag, max_bits)  # saturate (covers inf); NaN fixed up below
+    e32 = mag >> 23  # biased fp32 exponent
+    man = mag & 0x7FFFFF
+    # target exponent (unbiased) and significand with hidden bit
+    e_unb = e32 - 127
+    sig = np.where(e32 > 0, man | 0x800000, man)  # 24-bit significand; fp32 subnormals: no hidden bit
+    e_unb = np.where(e32 > 0, e_unb, -126)
+    emin = 1 - bias  # exponent of min normal
+    # number of fp32 fraction bits to drop: 23 - m for normals, more below emin
+    drop = (23 - m) + np.maximum(emin - e_unb, 0)
+    drop = np.minimum(drop, 40)
+    half = np.int64(1) << (drop - 1)
+    mask = (np.int64(1) << drop) - 1
+    q = sig >> drop
+    rem = sig & mask
+    q = q + ((rem > half) | ((rem == half) & ((q & 1) == 1))).astype(np.int64)
+    # q is in units of 2^(max(e_unb,emin) - m).  Build the byte arithmetically:
+    # normal: q in [2^m, 2^(m+1)] ; byte = ((e_unb + bias - 1) << m) + q handles mantissa carry.
+    e_eff = np.maximum(e_unb, emin)
+    byte = ((e_eff + bias - 1) << m) + q
+    byte = np.where(e_unb < emin, q, byte)  # subnormal / rounds-up-to-min-normal: exponent field comes from q
+    byte = np.where(mag == 0, 0, byte)
+    byte = byte | (sign << 7)
+    byte = np.where(isnan, FP8_NAN_BYTE, byte)
+    return byte.astype(np.uint8)
+
+
+# --------------------------------------------------------------------------- delayed scaling (K1/K2/K3)
+def amax_f32(x: np.ndarray) -> np.float32:
+    """max(|x|) with fmaxf semantics: NaN elements are ignored, +-inf propagates; empty -> 0."""
+    a = np.abs(np.asarray(x, dtype=np.float32)).ravel()
+    a = a[~np.isnan(a)]
+    return np.float32(a.max()) if a.size else np.float32(0.0)
+
+
+def quantize_delayed(x_bf16_bits: np.ndarray, scale: np.float32, fmt: int):
+    """K1: y = sat_cast(x_f32 * scale) RNE; amax over the *unscaled* input.
+
+    x is given as bf16 bit patterns [rows, cols]; returns (bytes[rows, cols], amax f32).
+    The product x*scale is a single IEEE float32 multiply.
+    """
+    x = bf16_bits_to_f32(x_bf16_bits)
+    with np.errstate(over="ignore", invalid="ignore"):
+        y = x * np.float32(scale)
+    return fp8_encode_sat(y, fmt), amax_f32(x)
+
+
+def quantize_delayed_transpose(x_bf16_bits, scale, fmt):
+    """K2: K1 plus the transposed fp8 copy used by the dgrad / wgrad GEMMs."""
+    q, amax = quantize_delayed(x_bf16_bits, scale, fmt)
+    return q, np.ascontiguousarray(q.T), amax
+
+
+FLT_MAX = np.finfo(np.float32).max
+
+
+def scale_update(amax_history: np.ndarray, scale: np.ndarray, fp8_max, margin: int = 0,
+                 algo: str = "max"):
+    """K3: TE fused amax-and-scale update, float32 arithmetic.
+
+    amax_history [H, S] (row 0 = this iteration's amax), scale [S]; fp8_max scalar or [S].
+    Returns (new_history, new_scale, new_scale_inv).
+    """
+    h = np.array(amax_history, dtype=np.float32, copy=True)
+    scale = np.asarray(scale, dtype=np.float32)
+    fp8_max = np.broadcast_to(np.asarray(fp8_max, dtype=np.float32), scale.shape)
+    if algo == "max":
+        with np.errstate(invalid="ignore"):
+            # fmaxf semantics: ignore NaN unless every entry is NaN
+            amax = np.where(np.all(np.isnan(h), axis=0), np.float32(np.nan),
+                            np.nanmax(np.where(np.isnan(h), -np.inf, h), axis=0)).astype(np.float32)
+    elif algo == "most_recent":
+        amax = h[0].copy()
+    else:
+        raise ValueError(algo)
+    h = np.roll(h, -1, axis=0)
+    h[0, :] = 0.0
+    with np.errstate(divide="ignore", over="ignore", invalid="ignore"):
+        sf = (fp8_max / amax).astype(np.float32)
+        sf = (sf / np.float32(2.0 ** margin)).astype(np.float32)
+    keep = ~(amax > 0) | ~np.isfinite(amax)
+    sf = np.where(np.isinf(sf), np.float32(FLT_MAX), sf)
+    sf = np.where(keep, scale, sf).astype(np.float32)
+    with np.errstate(divide="ignore"):
+        inv = (np.float32(1.0) / sf).astype(np.float32)
+    return h, sf, inv
+
+
+# --------------------------------------------------------------------------- FP8 GEMM (K4-K6)
+def gemm_fp8_tn(a8, b8, fmt_a, fmt_b, sa_inv, sb_inv, bias_bf16_bits=None, out_f32=False):
+    """D[M,N] = (A[M,K] . B[N,K]^T) * (sa_inv*sb_inv) (+bias) -> bf16 bits (or f32).
+
+    Accumulation in float64 (products of two fp8 values are exact; the sum is the
+    infinitely-precise reference the fp32-accumulating kernel is compared against).
+    alpha = sa_inv*sb_inv is one float32 product, as in the kernel epilogue.
+    """
+    a = fp8_decode(a8, fmt_a).astype(np.float64)
+    b = fp8_decode(b8, fmt_b).astype(np.float64)
+    alpha = np.float32(sa_inv) * np.float32(sb_inv)
+    d = (a @ b.T) * np.float64(alpha)
+    if bias_bf16_bits is not None:
+        d = d + bf16_bits_to_f32(bias_bf16_bits).astype(np.float64)[None, :]
+    d = d.astype(np.float32)
+    return d if out_f32 else f32_to_bf16_bits(d)
+
+
+def gemm_tolerance(ref_f32: np.ndarray) -> np.ndarray:
+    """|delta| <= 2^-7 |ref| + 1e-3 rms(ref)  (SURVEY 8c): 1 bf16 ulp + fp32 accumulation-order noise."""
+    ref = np.asarray(ref_f32, dtype=np.float64)
+    rms = np.sqrt(np.mean(ref * ref)) if ref.size else 0.0
+    return 2.0 ** -7 * np.abs(ref) + 1e-3 * rms
+
+
+# --------------------------------------------------------------------------- MXFP8 (K7/K8)
+MX_BLOCK = 32
+_MAX_NORM_RCP = {E4M3: np.float32(1.0) / np.float32(448.0), E5M2: np.float32(1.0) / np.float32(57344.0)}
+
+
+def float_to_e8m0_roundup(val: np.ndarray) -> np.ndarray:
+    """E8M0 biased exponent of `val`, rounded UP to the next power of two (TE MXFP8 rule).
+
+    NaN -> 0xFF, inf -> 0xFE, 0 -> 0.  For fp32 subnormal inputs (exponent field 0) the
+    exponent is bumped only if the mantissa exceeds 0x400000 (i.e. val > 2^-127).
+    """
+    val = np.ascontiguousarray(val, dtype=np.float32)
+    u = val.view(np.uint32)
+    exp = ((u >> 23) & 0xFF).astype(np.int64)
+    man = (u & 0x7FFFFF).astype(np.int64)
+    bump = (man > 0) & (exp != 0xFE) & ~((exp == 0) & (man <= 0x400000))
+    out = exp + bump.astype(np.int64)
+    out = np.where(np.isnan(val), 0xFF, out)
+    out = np.where(np.isinf(val), 0xFE, out)
+    out = np.where(val == 0, 0, out)
+    return out.astype(np.uint8)
+
+
+def e8m0_to_f32(e: np.ndarray) -> np.ndarray:
+    e = np.asarray(e, dtype=np.uint8).astype(np.int64)
+    with np.errstate(over="ignore"):
+        v = np.ldexp(np.float64(1.0), e - 127).astype(np.float32)
+    return np.where(e == 0xFF, np.float32(np.nan), v)
+
+
+def mxfp8_quantize_rowwise(x_bf16_bits: np.ndarray, fmt: int = E4M3):
+    """K7: one E8M0 scale per 32 consecutive elements of the LAST axis.
+
+    Returns (fp8 bytes [R, C], e8m0 bytes [R, C/32]).  y = sat_cast(x * 2^(127-e)).
+    """
+    x = bf16_bits_to_f32(x_bf16_bits)
+    r, c = x.shape
+    assert c % MX_BLOCK == 0
+    xb = x.reshape(r, c // MX_BLOCK, MX_BLOCK)
+    ab = np.abs(xb)
+    ab = np.where(np.isnan(ab), np.float32(0), ab)  # fmaxf semantics
+    amax_b = ab.max(axis=2).astype(np.float32)
+    e = float_to_e8m0_roundup((amax_b * _MAX_NORM_RCP[fmt]).astype(np.float32))
+    with np.errstate(over="ignore", invalid="ignore"):
+        inv = np.ldexp(np.float32(1.0), 127 - e.astype(np.int64)).astype(np.float32)  # 2^(127-e), exact
+        y = (xb * inv[:, :, None]).astype(np.float32)
+    return fp8_encode_sat(y, fmt).reshape(r, c), e
+
+
+def mxfp8_quantize_colwise(x_bf16_bits: np.ndarray, fmt: int = E4M3):
+    """K7 column-wise copy: blocks of 32 along the FIRST axis, returned TRANSPOSED.
+
+    Returns (fp8 bytes [C, R], e8m0 bytes [C, R/32]) i.e. the row-wise quantisation of x^T,
+    which is the operand layout the TN GEMM consumes for dgrad / wgrad.
+    """
+    xt = np.ascontiguousarray(np.asarray(x_bf16_bits, dtype=np.uint16).T)
+    return mxfp8_quantize_rowwise(xt, fmt)
+
+
+def gemm_mxfp8_tn(a8, a_e8m0, b8, b_e8m0, fmt_a=E4M3, fmt_b=E4M3, bias_bf16_bits=None, out_f32=False):
+    """K8: D = sum_blocks 2^(ea+eb-254) * sum_32 a8*b8 (+bias) -> bf16 bits."""
+    a = fp8_decode(a8, fmt_a).astype(np.float64)
+    b = fp8_decode(b8, fmt_b).astype(np.float64)
+    sa = np.repeat(e8m0_to_f32(a_e8m0).astype(np.float64), MX_BLOCK, axis=1)
+    sb = np.repeat(e8m0_to_f32(b_e8m0).astype(np.float64), MX_BLOCK, axis=1)
+    d = (a * sa) @ (b * sb).T
+    if bias_bf16_bits is not None:
+        d = d + bf16_bits_to_f32(bias_bf16_bits).astype(np.float64)[None, :]
+    d = d.astype(np.float32)
+    return d if out_f32 else f32_to_bf16_bits(d)
+
+
+# --------------------------------------------------------------------------- one FP8 Linear, fwd + bwd, with state
+class DelayedLinearOracle:
+    """One te.Linear under DelayedScaling: state carried across steps.
+
+    fwd slots: 0 input, 1 weight, 2 output(unused);  bwd slots: 0 grad_output, 1 grad_input(unused).
+    fmt_fwd/fmt_bwd follow recipe.Format: E4M3 -> (E4M3, E4M3); HYBRID -> (E4M3, E5M2).
+    """
+
+    def __init__(self, fmt_fwd=E4M3, fmt_bwd=E5M2, history_len=16, algo="max", margin=0):
+        self.fmt_fwd, self.fmt_bwd = fmt_fwd, fmt_bwd
+        self.algo, self.margin = algo, margin
+        self.h_fwd = np.zeros((history_len, 3), np.float32)
+        self.h_bwd = np.zeros((history_len, 2), np.float32)
+        self.s_fwd = np.ones(3, np.float32)
+        self.s_bwd = np.ones(2, np.float32)
+        self.si_fwd = np.ones(3, np.float32)
+        self.si_bwd = np.ones(2, np.float32)
+
+    def forward(self, x_bits, w_bits, bias_bits=None):
+        x8, x8t, ax = quantize_delayed_transpose(x_bits, self.s_fwd[0], self.fmt_fwd)
+        w8, w8t, aw = quantize_delayed_transpose(w_bits, self.s_fwd[1], self.fmt_fwd)
+        self.h_fwd[0, 0] = max(self.h_fwd[0, 0], ax)
+        self.h_fwd[0, 1] = max(self.h_fwd[0, 1], aw)
+        y = gemm_fp8_tn(x8, w8, self.fmt_fwd, self.fmt_fwd, self.si_fwd[0], self.si_fwd[1], bias_bits)
+        self.saved = (x8t, w8t, self.si_fwd[0].copy(), self.si_fwd[1].copy())
+        return y
+
+    def end_forward(self):
+        fmax = FP8_MAX[self.fmt_fwd]
+        self.h_fwd, self.s_fwd, self.si_fwd = scale_update(self.h_fwd, self.s_fwd, fmax, self.margin, self.algo)
+
+    def backward(self, dy_bits):
+        x8t, w8t, six, siw = self.saved
+        g8, g8t, ag = quantize_delayed_transpose(dy_bits, self.s_bwd[0], self.fmt_bwd)
+        self.h_bwd[0, 0] = max(self.h_bwd[0, 0], ag)
+        sig = self.si_bwd[0]
+        dx = gemm_fp8_tn(g8, w8t, self.fmt_bwd, self.fmt_fwd, sig, siw)      # [M,N].[K,N]^T -> [M,K]
+        dw = gemm_fp8_tn(g8t, x8t, self.fmt_bwd, self.fmt_fwd, sig, six)     # [N,M].[K,M]^T -> [N,K]
+        db = f32_to_bf16_bits(bf16_bits_to_f32(dy_bits).astype(np.float64).sum(axis=0).astype(np.float32))
+        return dx, dw, db
+
+    def end_backward(self):
+        fmax = FP8_MAX[self.fmt_bwd]
+        self.h_bwd, self.s_bwd, self.si_bwd = scale_update(self.h_bwd, self.s_bwd, fmax, self.margin, self.algo)
+
+
+def mxfp8_linear_fwd_bwd(x_bits, w_bits, dy_bits, bias_bits=None, fmt=E4M3):
+    """One te.Linear under MXFP8BlockScaling(E4M3) (te_llama_mxfp8.py:28-29): stateless."""
+    x8, xe = mxfp8_quantize_rowwise(x_bits, fmt)       # blocks along K
+    w8, we = mxfp8_quantize_rowwise(w_bits, fmt)
+    y = gemm_mxfp8_tn(x8, xe, w8, we, fmt, fmt, bias_bits)
+    g8, ge = mxfp8_quantize_rowwise(dy_bits, fmt)      # [M,N], blocks along N  (dgrad contracts N)
+    wt8, wte = mxfp8_quantize_colwise(w_bits, fmt)     # [K,N], blocks along N
+    dx = gemm_mxfp8_tn(g8, ge, wt8, wte, fmt, fmt)
+    gt8, gte = mxfp8_quantize_colwise(dy_bits, fmt)    # [N,M], blocks along M (wgrad contracts M)
+    xt8, xte = mxfp8_quantize_colwise(x_bits, fmt)     # [K,M], blocks along M
+    dw = gemm_mxfp8_tn(gt8, gte, xt8, xte, fmt, fmt)
+    db = f32_to_bf16_bits(bf16_bits_to_f32(dy_bits).astype(np.float64).sum(axis=0).astype(np.float32))
+    return y, dx, dw, db

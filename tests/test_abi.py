@@ -1,0 +1,52 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mi_fp8.h declares; argument checks
+that need no GPU work; the package refuses to run its ops on CPU tensors."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "mi_fp8.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_expected_entry_points():
+    syms = _declared_symbols()
+    for s in ("mi_cast_amax", "mi_scale_update", "mi_gemm_fp8", "mi_mxfp8_quantize", "mi_gemm_mxfp8",
+              "mi_last_error", "mi_abi_version"):
+        assert s in syms
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from llm_fp8_amd import _lib
+    lib = _lib.load()
+    for s in _declared_symbols():
+        assert hasattr(lib, s), f"libmi_fp8.so does not export {s}"
+        assert s in _lib.SIGNATURES, f"ctypes binding missing for {s}"
+    assert lib.mi_abi_version() == _lib.ABI_VERSION
+
+
+def test_argument_errors_are_reported_not_thrown():
+    from llm_fp8_amd import _lib
+    lib = _lib.load()
+    rc = lib.mi_cast_amax(None, None, None, None, None, 8, 8, 8, 8, 0, None)
+    assert rc == -1 and b"non-null" in lib.mi_last_error()
+    rc = lib.mi_scale_update(None, None, None, None, 16, 4, 0, 0, None)
+    assert rc == -1
+    rc = lib.mi_gemm_fp8(None, None, None, None, None, None, 16, 16, 16, 16, 16, 16, 0, 0, 0, 0, None)
+    assert rc == -1 and b"null operand" in lib.mi_last_error()
+    with pytest.raises(RuntimeError, match="null operand"):
+        _lib.check(rc, "mi_gemm_fp8")
+
+
+def test_ops_refuse_cpu_tensors():
+    from llm_fp8_amd.pytorch import ops
+    x = torch.zeros((8, 8), dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.cast_amax(x, torch.ones(1), None, 0)

@@ -1,0 +1,262 @@
+"""GPU parity tests: every HIP kernel behind the C ABI against the CPU oracle.
+Casts / scales / MX bytes: bit-exact.  GEMMs: |d| <= 2^-7 |ref| + 1e-3 rms(ref)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fp8_oracle as O
+from tests.util import assert_gemm_close, bf16_bits, bits_to_bf16, dequant_table, u8
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from llm_fp8_amd.pytorch import ops as _ops
+    from llm_fp8_amd import _lib
+    assert _lib.load().mi_device_supported() == 1, "not a gfx950 device"
+    return _ops
+
+
+def _f32(v, dev):
+    return torch.tensor([v], dtype=torch.float32, device=dev)
+
+
+# ----------------------------------------------------------------------------------------- K1/K2
+@pytest.mark.parametrize("fmt", [O.E4M3, O.E5M2])
+@pytest.mark.parametrize("scale", [1.0, 0.5, 3.7, 448.0 / 3.3, 1e-3, 1e4, 2.0 ** -20, 3e38])
+def test_cast_exhaustive_all_bf16(ops, dev, fmt, scale):
+    bits = np.arange(65536, dtype=np.uint32).astype(np.uint16).reshape(256, 256)
+    x = bits_to_bf16(bits, dev)
+    amax = torch.zeros(1, dtype=torch.float32, device=dev)
+    y, yT = ops.cast_amax(x, _f32(scale, dev), amax, fmt)
+    q, a = O.quantize_delayed(bits, np.float32(scale), fmt)
+    got = u8(y)
+    bad = np.nonzero(got != q)
+    assert bad[0].size == 0, f"{bad[0].size} byte mismatches, first: in={bits[bad][0]:#06x} got={got[bad][0]:#04x} want={q[bad][0]:#04x}"
+    np.testing.assert_array_equal(u8(yT), q.T)
+    assert amax.item() == a == np.inf
+
+
+@pytest.mark.parametrize("shape", [(8, 8), (16, 136), (136, 72), (1000, 264), (1024, 3072)])
+@pytest.mark.parametrize("fmt", [O.E4M3, O.E5M2])
+def test_cast_ragged_shapes_and_amax(ops, dev, shape, fmt):
+    g = torch.Generator().manual_seed(shape[0] * 7 + shape[1])
+    x = (torch.randn(shape, generator=g) * 3).to(torch.bfloat16)
+    x[0, 0] = float("nan")
+    bits = bf16_bits(x)
+    scale = np.float32(448.0 / 11.0)
+    amax = torch.full((1,), 0.25, dtype=torch.float32, device=dev)
+    y, yT = ops.cast_amax(x.to(dev), _f32(scale, dev), amax, fmt)
+    q, a = O.quantize_delayed(bits, scale, fmt)
+    np.testing.assert_array_equal(u8(y), q)
+    np.testing.assert_array_equal(u8(yT), q.T)
+    assert amax.item() == max(a, np.float32(0.25))
+    # y-only and yT-only variants, amax optional
+    y2, t2 = ops.cast_amax(x.to(dev), _f32(scale, dev), None, fmt, want_t=False)
+    assert t2 is None
+    np.testing.assert_array_equal(u8(y2), q)
+    y3, t3 = ops.cast_amax(x.to(dev), _f32(scale, dev), None, fmt, want_y=False)
+    assert y3 is None
+    np.testing.assert_array_equal(u8(t3), q.T)
+
+
+def test_cast_into_slices_of_fused_buffers(ops, dev):
+    """q|k|v weights are cast into row-slices of ONE fused operand and share one amax slot
+    (SURVEY App. A "Fused-QKV"; te_llama.py:194-217)."""
+    g = torch.Generator().manual_seed(11)
+    K = 64
+    parts = [(torch.randn(n, K, generator=g) * (i + 1)).to(torch.bfloat16) for i, n in enumerate((48, 16, 16))]
+    N = sum(p.shape[0] for p in parts)
+    y = torch.zeros((N, K), dtype=torch.uint8, device=dev)
+    yT = torch.zeros((K, N), dtype=torch.uint8, device=dev)
+    amax = torch.zeros(1, dtype=torch.float32, device=dev)
+    r = 0
+    for p in parts:
+        n = p.shape[0]
+        ops.cast_amax(p.to(dev), _f32(2.0, dev), amax, O.E4M3, y=y[r:r + n], yT=yT[:, r:r + n])
+        r += n
+    full = torch.cat(parts, 0)
+    q, a = O.quantize_delayed(bf16_bits(full), np.float32(2.0), O.E4M3)
+    np.testing.assert_array_equal(u8(y), q)
+    np.testing.assert_array_equal(u8(yT), q.T)
+    assert amax.item() == a
+
+
+def test_cast_rejects_bad_args(ops, dev):
+    x = torch.zeros((12, 8), dtype=torch.bfloat16, device=dev)
+    with pytest.raises(RuntimeError, match="multiples of 8"):
+        ops.cast_amax(x, _f32(1.0, dev), None, O.E4M3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.cast_amax(x.cpu(), _f32(1.0, dev), None, O.E4M3)
+
+
+@pytest.mark.parametrize("fmt", [O.E4M3, O.E5M2])
+def test_cast_full_size_properties(ops, dev, fmt):
+    """BASELINE size (M=8192 x K=3072): transpose consistency, amax, idempotent dequant bound."""
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn((8192, 3072), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    scale = 448.0 / 8.0 if fmt == O.E4M3 else 57344.0 / 8.0
+    amax = torch.zeros(1, dtype=torch.float32, device=dev)
+    y, yT = ops.cast_amax(x, _f32(scale, dev), amax, fmt)
+    assert torch.equal(yT, y.t().contiguous())
+    assert amax.item() == x.float().abs().max().item()
+    deq = dequant_table(fmt, dev)[y.long()] / scale
+    rel = ((deq - x.float()).abs() / x.float().abs().clamp_min(2.0 ** -6)).max().item()
+    assert rel <= (2.0 ** -4 if fmt == O.E4M3 else 2.0 ** -3) * 1.01
+
+
+# ----------------------------------------------------------------------------------------- K3
+@pytest.mark.parametrize("H,algo,margin", [(16, "max", 0), (1024, "most_recent", 0), (4, "max", 2), (1, "max", 0),
+                                            (300, "max", 0)])
+def test_scale_update_trajectory(ops, dev, H, algo, margin):
+    S = 37
+    rng = np.random.default_rng(H)
+    hist = np.zeros((H, S), np.float32)
+    scale = np.ones(S, np.float32)
+    fmax = np.where(np.arange(S) % 3 == 0, 57344.0, 448.0).astype(np.float32)
+    d_hist = torch.zeros((H, S), dtype=torch.float32, device=dev)
+    d_scale = torch.ones(S, dtype=torch.float32, device=dev)
+    d_inv = torch.ones(S, dtype=torch.float32, device=dev)
+    d_fmax = torch.from_numpy(fmax).to(dev)
+    for step in range(24):
+        am = np.exp(rng.normal(size=S) * 4).astype(np.float32)
+        am[rng.random(S) < 0.2] = 0.0
+        if step == 5:
+            am[1] = np.inf
+        if step == 7:
+            am[2] = 1e-42  # subnormal amax -> fp8_max/amax overflows -> FLT_MAX guard
+        if step == 9:
+            am[3] = 3e38
+        hist[0] = am
+        d_hist[0] = torch.from_numpy(am).to(dev)
+        hist, scale, inv = O.scale_update(hist, scale, fmax, margin, algo)
+        ops.scale_update(d_hist, d_scale, d_inv, d_fmax, margin, algo)
+        np.testing.assert_array_equal(d_hist.cpu().numpy().view(np.uint32), hist.view(np.uint32), err_msg=f"hist step {step}")
+        np.testing.assert_array_equal(d_scale.cpu().numpy().view(np.uint32), scale.view(np.uint32), err_msg=f"scale step {step}")
+        np.testing.assert_array_equal(d_inv.cpu().numpy().view(np.uint32), inv.view(np.uint32), err_msg=f"inv step {step}")
+
+
+# ----------------------------------------------------------------------------------------- K4-K6
+def _rand_fp8(shape, fmt, seed, spread=1.0):
+    rng = np.random.default_rng(seed)
+    v = (rng.normal(size=shape) * spread * np.exp(rng.normal(size=shape))).astype(np.float32)
+    return O.fp8_encode_sat(v, fmt)
+
+
+GEMM_SHAPES = [(64, 96, 128), (16, 16, 16), (8, 24, 48), (200, 136, 400), (256, 256, 128), (256, 512, 384),
+               (512, 256, 3072), (256, 5120, 3072), (768, 1024, 256)]
+
+
+@pytest.mark.parametrize("shape", GEMM_SHAPES)
+@pytest.mark.parametrize("fa,fb", [(O.E4M3, O.E4M3), (O.E5M2, O.E4M3), (O.E4M3, O.E5M2), (O.E5M2, O.E5M2)])
+@pytest.mark.parametrize("algo", [0, 1])
+def test_gemm_fp8_vs_oracle(ops, dev, shape, fa, fb, algo):
+    M, N, K = shape
+    if algo == 1 and M * N * K > 256 * 512 * 3072:
+        pytest.skip("generic path covered at smaller sizes")
+    a8 = _rand_fp8((M, K), fa, 1 + M, 4.0 if fa == O.E4M3 else 64.0)
+    b8 = _rand_fp8((N, K), fb, 2 + N, 4.0 if fb == O.E4M3 else 64.0)
+    sa, sb = np.float32(1 / 7.3), np.float32(1 / 0.011)
+    rng = np.random.default_rng(3)
+    bias = O.f32_to_bf16_bits(rng.normal(size=N).astype(np.float32) * 10)
+    for use_bias in (False, True):
+        ref = O.gemm_fp8_tn(a8, b8, fa, fb, sa, sb, bias if use_bias else None, out_f32=True)
+        d = ops.gemm_fp8(torch.from_numpy(a8).to(dev), torch.from_numpy(b8).to(dev), _f32(sa, dev), _f32(sb, dev),
+                         fa, fb, bias=bits_to_bf16(bias, dev) if use_bias else None, algo=algo)
+        assert_gemm_close(d.float().cpu().numpy(), ref, f"gemm {shape} fmt({fa},{fb}) algo {algo} bias {use_bias}")
+    # fp32 output
+    d32 = ops.gemm_fp8(torch.from_numpy(a8).to(dev), torch.from_numpy(b8).to(dev), _f32(sa, dev), _f32(sb, dev),
+                       fa, fb, out_dtype=torch.float32, algo=algo)
+    ref = O.gemm_fp8_tn(a8, b8, fa, fb, sa, sb, None, out_f32=True)
+    np.testing.assert_allclose(d32.cpu().numpy(), ref, rtol=2e-5, atol=1e-5 * np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+def test_gemm_identity_with_asymmetric_b(ops, dev, algo):
+    """A = I (padded), B asymmetric small integers: exact result, catches row/col swaps and K-permutation
+    mismatches between the A and B fragments."""
+    M = N = K = 256
+    a = np.zeros((M, K), np.float32)
+    a[np.arange(M), np.arange(K)] = 1.0
+    b = ((np.arange(N)[:, None] * 3 + np.arange(K)[None, :] * 5) % 17 - 8).astype(np.float32)
+    a8, b8 = O.fp8_encode_sat(a, O.E4M3), O.fp8_encode_sat(b, O.E4M3)
+    d = ops.gemm_fp8(torch.from_numpy(a8).to(dev), torch.from_numpy(b8).to(dev), _f32(1.0, dev), _f32(1.0, dev),
+                     O.E4M3, O.E4M3, out_dtype=torch.float32, algo=algo)
+    np.testing.assert_array_equal(d.cpu().numpy(), b.T)
+
+
+def test_gemm_full_size_vs_device_fp32_matmul(ops, dev):
+    """BASELINE 3B qkv shape (8192 x 5120 x 3072): compare with an fp32 matmul of the dequantised operands
+    computed on the device by torch (independent of our kernel), plus linearity in alpha."""
+    M, N, K = 8192, 5120, 3072
+    g = torch.Generator(device=dev).manual_seed(9)
+    a8 = torch.randint(0, 256, (M, K), generator=g, device=dev, dtype=torch.uint8)
+    b8 = torch.randint(0, 256, (N, K), generator=g, device=dev, dtype=torch.uint8)
+    a8[(a8 & 0x7F) == 0x7F] = 0  # no NaN bytes
+    b8[(b8 & 0x7F) == 0x7F] = 0
+    a8 &= 0xBF  # keep magnitudes < 2 so the fp32 reference matmul is well conditioned
+    b8 &= 0xBF
+    ta, tb = dequant_table(O.E4M3, dev), dequant_table(O.E4M3, dev)
+    ref = (ta[a8.long()] @ tb[b8.long()].t())
+    one, half = _f32(1.0, dev), _f32(0.5, dev)
+    d = ops.gemm_fp8(a8, b8, one, one, O.E4M3, O.E4M3, out_dtype=torch.float32)
+    rms = ref.pow(2).mean().sqrt().item()
+    assert ((d - ref).abs() <= 1e-4 * ref.abs() + 1e-4 * rms).all()
+    d2 = ops.gemm_fp8(a8, b8, half, one, O.E4M3, O.E4M3, out_dtype=torch.float32)
+    assert torch.equal(d2, d * 0.5)
+    dbf = ops.gemm_fp8(a8, b8, one, one, O.E4M3, O.E4M3)
+    assert torch.equal(dbf, d.to(torch.bfloat16))
+
+
+def test_gemm_rejects_bad_shapes(ops, dev):
+    a = torch.zeros((16, 24), dtype=torch.uint8, device=dev)
+    b = torch.zeros((16, 24), dtype=torch.uint8, device=dev)
+    with pytest.raises(RuntimeError, match="K of 16"):
+        ops.gemm_fp8(a, b, _f32(1, dev), _f32(1, dev), 0, 0)
+    a = torch.zeros((64, 128), dtype=torch.uint8, device=dev)
+    with pytest.raises(RuntimeError, match="needs M,N"):
+        ops.gemm_fp8(a, a, _f32(1, dev), _f32(1, dev), 0, 0, algo=2)
+
+
+# ----------------------------------------------------------------------------------------- K7/K8
+@pytest.mark.parametrize("shape", [(32, 32), (64, 96), (160, 416), (1024, 3072)])
+@pytest.mark.parametrize("fmt", [O.E4M3, O.E5M2])
+def test_mxfp8_quantize_bitexact(ops, dev, shape, fmt):
+    g = torch.Generator().manual_seed(shape[1])
+    x = torch.randn(shape, generator=g) * torch.exp(torch.randn(shape[0], 1, generator=g) * 5)
+    x[:, :32] = 0  # all-zero blocks
+    x[1, 40] = float("inf")
+    x[2, 41] = float("nan")
+    x[3, 33:64] = 1e-30
+    x = x.to(torch.bfloat16)
+    bits = bf16_bits(x)
+    y_row, s_row, y_colT, s_colT = ops.mxfp8_quantize(x.to(dev), fmt)
+    q, e = O.mxfp8_quantize_rowwise(bits, fmt)
+    qc, ec = O.mxfp8_quantize_colwise(bits, fmt)
+    np.testing.assert_array_equal(u8(s_row), e)
+    np.testing.assert_array_equal(u8(y_row), q)
+    np.testing.assert_array_equal(u8(s_colT), ec)
+    np.testing.assert_array_equal(u8(y_colT), qc)
+    yr, sr, yc, sc = ops.mxfp8_quantize(x.to(dev), fmt, colwise=False)
+    assert yc is None and sc is None
+    np.testing.assert_array_equal(u8(yr), q)
+    yr, sr, yc, sc = ops.mxfp8_quantize(x.to(dev), fmt, rowwise=False)
+    assert yr is None
+    np.testing.assert_array_equal(u8(yc), qc)
+
+
+@pytest.mark.parametrize("shape", [(32, 32, 32), (64, 96, 128), (96, 160, 320), (256, 512, 1024)])
+def test_gemm_mxfp8_vs_oracle(ops, dev, shape):
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + K)
+    a = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, K // 32, generator=g).repeat_interleave(32, 1) * 2)).to(torch.bfloat16)
+    b = (torch.randn(N, K, generator=g) * torch.exp(torch.randn(N, K // 32, generator=g).repeat_interleave(32, 1) * 2)).to(torch.bfloat16)
+    a8, ae = O.mxfp8_quantize_rowwise(bf16_bits(a))
+    b8, be = O.mxfp8_quantize_rowwise(bf16_bits(b))
+    ref = O.gemm_mxfp8_tn(a8, ae, b8, be, out_f32=True)
+    t = lambda v: torch.from_numpy(v).to(dev)
+    d = ops.gemm_mxfp8(t(a8), t(ae), t(b8), t(be), out_dtype=torch.float32)
+    np.testing.assert_allclose(d.cpu().numpy(), ref, rtol=2e-5, atol=1e-5 * np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+    dbf = ops.gemm_mxfp8(t(a8), t(ae), t(b8), t(be))
+    assert_gemm_close(dbf.float().cpu().numpy(), ref, f"mx gemm {shape}")

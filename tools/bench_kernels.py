@@ -1,0 +1,70 @@
+"""Micro-benchmarks of the HIP kernels (GPU box).  Prints one line per (kernel, shape, algo)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from llm_fp8_amd.pytorch import ops  # noqa: E402
+
+SHAPES_3B = {"qkv": (8192, 5120, 3072), "o": (8192, 3072, 3072), "fc1": (8192, 16384, 3072), "fc2": (8192, 3072, 8192)}
+
+
+def time_fn(fn, iters=20, warmup=5):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def rand_fp8(shape, dev, g):
+    t = torch.randint(0, 256, shape, generator=g, device=dev, dtype=torch.uint8)
+    t[(t & 0x7F) >= 0x78] &= 0x3F  # keep |v| modest, no NaN
+    return t
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--algos", default="2")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--which", default="gemm,cast,mx")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(0)
+    one = torch.ones(1, device=dev)
+    if "gemm" in args.which:
+        for name, (M, N, K) in SHAPES_3B.items():
+            for kind, (m, n, k) in (("fprop", (M, N, K)), ("dgrad", (M, K, N)), ("wgrad", (N, K, M))):
+                a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
+                out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+                for algo in [int(x) for x in args.algos.split(",")]:
+                    t = time_fn(lambda: ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=algo), args.iters)
+                    tf = 2.0 * m * n * k / t / 1e12
+                    print(f"gemm {name:4s} {kind:5s} {m:6d}x{n:6d}x{k:6d} algo {algo}: {t*1e6:9.1f} us {tf:8.1f} TFLOP/s "
+                          f"({tf/5000*100:5.1f}% of 5 PF)", flush=True)
+    if "cast" in args.which:
+        for (R, C) in ((8192, 3072), (8192, 16384), (16384, 3072), (8192, 8192)):
+            x = torch.randn((R, C), device=dev, dtype=torch.float32, generator=g).to(torch.bfloat16)
+            amax = torch.zeros(1, device=dev)
+            y = torch.empty((R, C), dtype=torch.uint8, device=dev)
+            yT = torch.empty((C, R), dtype=torch.uint8, device=dev)
+            t = time_fn(lambda: ops.cast_amax(x, one, amax, 0, y=y, yT=yT), args.iters)
+            print(f"cast+T {R}x{C}: {t*1e6:8.1f} us {4.0*R*C/t/1e9:8.1f} GB/s (alg 4 B/elem)", flush=True)
+            t = time_fn(lambda: ops.cast_amax(x, one, amax, 0, y=y, want_t=False), args.iters)
+            print(f"cast   {R}x{C}: {t*1e6:8.1f} us {3.0*R*C/t/1e9:8.1f} GB/s (alg 3 B/elem)", flush=True)
+    if "mx" in args.which:
+        for (R, C) in ((8192, 3072), (8192, 16384)):
+            x = torch.randn((R, C), device=dev, dtype=torch.float32, generator=g).to(torch.bfloat16)
+            t = time_fn(lambda: ops.mxfp8_quantize(x), args.iters)
+            print(f"mxquant {R}x{C}: {t*1e6:8.1f} us {(4.0+2/32)*R*C/t/1e9:8.1f} GB/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
