@@ -69,10 +69,10 @@ int mi_cast_amax(const void* x_bf16, void* y_fp8, void* yT_fp8, const float* sca
  *   hist = roll(hist, -1, dim 0); hist[0][s] = 0
  *   sf = (fp8_max[s] / amax) / 2^margin ; keep old scale if !(amax > 0) or !isfinite(amax);
  *   sf = FLT_MAX if isinf(sf) ; scale[s] = sf ; scale_inv[s] = 1 / sf
- * amax_history: [H, S] fp32 row-major.  H <= 4096.
+ * amax_history: [H, S] fp32, row stride `ld` >= S floats (a used prefix of a larger arena).  H <= 4096.
  */
 int mi_scale_update(float* amax_history, float* scale, float* scale_inv, const float* fp8_max,
-                    int H, int S, int margin, int algo, void* stream);
+                    int H, int S, int64_t ld, int margin, int algo, void* stream);
 
 /*
  * K4/K5/K6  FP8 x FP8 -> bf16 GEMM on gfx950 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, unit scales)

@@ -3,7 +3,7 @@
 // HBM-bound: 2 B read + 1 B (K1) or 2 B (K2) written per element.  One workgroup owns a
 // 128x128 element tile (4 waves as 2x2, one 64x64 sub-tile per wave, one 8x8 block per lane).
 //  - loads : 8 x 16 B per lane; the 8 lanes that share a row cover one full 128-B line.
-//  - amax  : fmaxf in registers -> wave shuffle (DPP) -> LDS across the 4 waves -> ONE
+//  - amax  : fmaxf in registers (NaN-screened: fmaxf semantics, NaN elements are ignored) -> wave shuffle (DPP) -> LDS across the 4 waves -> ONE
 //            atomicMax per workgroup on the float's bit pattern (non-negative floats order
 //            like unsigned ints).
 //  - y     : 8 B per lane per row (64-B runs per wave, 128-B lines per workgroup).
@@ -14,22 +14,6 @@
 #include "mi_common.h"
 
 namespace mi {
-
-// v_perm_b32: result byte i = byte sel[i] of the 8-byte pool {lo = bytes 0..3, hi = bytes 4..7}
-__device__ __forceinline__ u32 bperm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
-
-// 4x4 byte transpose: in r[i] = row i (byte j = col j) -> out c[j] = col j (byte i = row i)
-__device__ __forceinline__ void transpose4x4(u32 r0, u32 r1, u32 r2, u32 r3, u32& c0, u32& c1, u32& c2,
-                                             u32& c3) {
-  u32 t01l = bperm(r1, r0, 0x05010400u);  // [r0b0, r1b0, r0b1, r1b1]
-  u32 t01h = bperm(r1, r0, 0x07030602u);  // [r0b2, r1b2, r0b3, r1b3]
-  u32 t23l = bperm(r3, r2, 0x05010400u);
-  u32 t23h = bperm(r3, r2, 0x07030602u);
-  c0 = bperm(t23l, t01l, 0x05040100u);  // [t01l.b0, t01l.b1, t23l.b0, t23l.b1]
-  c1 = bperm(t23l, t01l, 0x07060302u);
-  c2 = bperm(t23h, t01h, 0x05040100u);
-  c3 = bperm(t23h, t01h, 0x07060302u);
-}
 
 template <int FMT, bool WRITE_Y, bool WRITE_T>
 __global__ __launch_bounds__(256) void cast_amax_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ y,
@@ -49,6 +33,12 @@ __global__ __launch_bounds__(256) void cast_amax_kernel(const uint16_t* __restri
     const uint16_t* src = x + (int64_t)r0 * cols + c0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) raw[i] = *reinterpret_cast<const v4i*>(src + (int64_t)i * cols);
+    u32 screen = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) screen = nan_screen(screen, (u32)raw[i][j]);
+    const bool has_nan = nan_seen(screen);
     u32 lo[8], hi[8];  // fp8 bytes of row i: lo = cols 0..3, hi = cols 4..7
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -59,8 +49,13 @@ __global__ __launch_bounds__(256) void cast_amax_kernel(const uint16_t* __restri
         f[2 * j] = __uint_as_float(w << 16);
         f[2 * j + 1] = __uint_as_float(w & 0xFFFF0000u);
       }
+      if (__builtin_expect(has_nan, 0)) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(f[j]));
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, (f[j] != f[j]) ? 0.0f : fabsf(f[j]));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(f[j]));
+      }
       lo[i] = cvt4_fp8<FMT>(f[0] * scale, f[1] * scale, f[2] * scale, f[3] * scale);
       hi[i] = cvt4_fp8<FMT>(f[4] * scale, f[5] * scale, f[6] * scale, f[7] * scale);
     }

@@ -82,6 +82,32 @@ __device__ __forceinline__ u32 cvt4_fp8(float v0, float v1, float v2, float v3) 
   return u;
 }
 
+// NaN screen on raw bf16 pairs: running packed-u16 max of the magnitudes; any lane value > 0x7F80
+// afterwards means "this thread saw a NaN".  (v_max_f32 in IEEE mode turns max(a, sNaN) into qNaN
+// and so forgets `a`; threads that saw a NaN take a sanitising slow path instead.)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32 nan_screen(u32 acc, u32 w) {
+  u16x2 a = __builtin_bit_cast(u16x2, acc), b = __builtin_bit_cast(u16x2, w & 0x7FFF7FFFu);
+  return __builtin_bit_cast(u32, __builtin_elementwise_max(a, b));
+}
+__device__ __forceinline__ bool nan_seen(u32 acc) { return max(acc & 0xFFFFu, acc >> 16) > 0x7F80u; }
+
+// v_perm_b32: result byte i = byte sel[i] of the 8-byte pool {lo = bytes 0..3, hi = bytes 4..7}
+__device__ __forceinline__ u32 bperm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+
+// 4x4 byte transpose: in r[i] = row i (byte j = col j) -> out c[j] = col j (byte i = row i)
+__device__ __forceinline__ void transpose4x4(u32 r0, u32 r1, u32 r2, u32 r3, u32& c0, u32& c1, u32& c2,
+                                             u32& c3) {
+  u32 t01l = bperm(r1, r0, 0x05010400u);  // [r0b0, r1b0, r0b1, r1b1]
+  u32 t01h = bperm(r1, r0, 0x07030602u);  // [r0b2, r1b2, r0b3, r1b3]
+  u32 t23l = bperm(r3, r2, 0x05010400u);
+  u32 t23h = bperm(r3, r2, 0x07030602u);
+  c0 = bperm(t23l, t01l, 0x05040100u);  // [t01l.b0, t01l.b1, t23l.b0, t23l.b1]
+  c1 = bperm(t23l, t01l, 0x07060302u);
+  c2 = bperm(t23h, t01h, 0x05040100u);
+  c3 = bperm(t23h, t01h, 0x07060302u);
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));

@@ -10,16 +10,6 @@
 
 namespace mi {
 
-__device__ __forceinline__ u32 bperm2(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
-__device__ __forceinline__ void tr4x4(u32 r0, u32 r1, u32 r2, u32 r3, u32& c0, u32& c1, u32& c2, u32& c3) {
-  u32 t01l = bperm2(r1, r0, 0x05010400u), t01h = bperm2(r1, r0, 0x07030602u);
-  u32 t23l = bperm2(r3, r2, 0x05010400u), t23h = bperm2(r3, r2, 0x07030602u);
-  c0 = bperm2(t23l, t01l, 0x05040100u);
-  c1 = bperm2(t23l, t01l, 0x07060302u);
-  c2 = bperm2(t23h, t01h, 0x05040100u);
-  c3 = bperm2(t23h, t01h, 0x07060302u);
-}
-
 // E8M0 biased exponent of (amax * 1/fp8_max), rounded up to the next power of two.
 __device__ __forceinline__ u32 e8m0_roundup(float val) {
   u32 u = __float_as_uint(val);
@@ -48,7 +38,9 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
   const int c0 = tile_c * 128 + (wave & 1) * 64 + (lane & 7) * 8;
   const float rcp = 1.0f / fp8_max_of<FMT>();
   const bool active = (r0 < rows) && (c0 < cols);
-  float f[8][8];
+  float f[8][8];  // values as cast
+  float g[8][8];  // |values| with NaN -> 0, for the block amax (fmaxf semantics)
+  u32 screen = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     v4i raw = {0, 0, 0, 0};
@@ -56,9 +48,21 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       u32 w = (u32)raw[j];
+      screen = nan_screen(screen, w);
       f[i][2 * j] = __uint_as_float(w << 16);
       f[i][2 * j + 1] = __uint_as_float(w & 0xFFFF0000u);
     }
+  }
+  if (__builtin_expect(nan_seen(screen), 0)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[i][j] = (f[i][j] != f[i][j]) ? 0.0f : fabsf(f[i][j]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[i][j] = fabsf(f[i][j]);
   }
   // NOTE: shuffles below are executed by every lane (inactive lanes carry zeros); rows/cols are
   // multiples of 32 so a 4-lane block group is all-active or all-inactive.
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
     for (int i = 0; i < 8; ++i) {
       float a = 0.0f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) a = fmaxf(a, fabsf(f[i][j]));
+      for (int j = 0; j < 8; ++j) a = fmaxf(a, g[i][j]);
       a = fmaxf(a, __shfl_xor(a, 1));
       a = fmaxf(a, __shfl_xor(a, 2));
       u32 e = e8m0_roundup(a * rcp);
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
     for (int j = 0; j < 8; ++j) {
       float a = 0.0f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) a = fmaxf(a, fabsf(f[i][j]));
+      for (int i = 0; i < 8; ++i) a = fmaxf(a, g[i][j]);
       a = fmaxf(a, __shfl_xor(a, 8));
       a = fmaxf(a, __shfl_xor(a, 16));
       u32 e = e8m0_roundup(a * rcp);
@@ -111,10 +115,10 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
     }
     if (active) {
       u32 a[4], b[4], c[4], d[4];
-      tr4x4(lo[0], lo[1], lo[2], lo[3], a[0], a[1], a[2], a[3]);
-      tr4x4(lo[4], lo[5], lo[6], lo[7], b[0], b[1], b[2], b[3]);
-      tr4x4(hi[0], hi[1], hi[2], hi[3], c[0], c[1], c[2], c[3]);
-      tr4x4(hi[4], hi[5], hi[6], hi[7], d[0], d[1], d[2], d[3]);
+      transpose4x4(lo[0], lo[1], lo[2], lo[3], a[0], a[1], a[2], a[3]);
+      transpose4x4(lo[4], lo[5], lo[6], lo[7], b[0], b[1], b[2], b[3]);
+      transpose4x4(hi[0], hi[1], hi[2], hi[3], c[0], c[1], c[2], c[3]);
+      transpose4x4(hi[4], hi[5], hi[6], hi[7], d[0], d[1], d[2], d[3]);
       uint8_t* dst = y_colT + (int64_t)c0 * rows + r0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {

@@ -12,7 +12,7 @@ constexpr int kMaxPerThread = 16;  // H <= 256 * 16
 
 __global__ __launch_bounds__(256) void scale_update_kernel(float* __restrict__ hist, float* __restrict__ scale,
                                                            float* __restrict__ scale_inv,
-                                                           const float* __restrict__ fp8_max, int H, int S,
+                                                           const float* __restrict__ fp8_max, int H, int64_t S,
                                                            float inv_margin_pow, int algo) {
   __shared__ float s_red[4];
   const int s = blockIdx.x, tid = threadIdx.x;
@@ -53,17 +53,17 @@ __global__ __launch_bounds__(256) void scale_update_kernel(float* __restrict__ h
 }  // namespace mi
 
 extern "C" int mi_scale_update(float* amax_history, float* scale, float* scale_inv, const float* fp8_max, int H,
-                               int S, int margin, int algo, void* stream) {
+                               int S, int64_t ld, int margin, int algo, void* stream) {
   MI_CHECK_ARG(amax_history && scale && scale_inv && fp8_max, "mi_scale_update: null pointer");
   MI_CHECK_ARG(H >= 1 && H <= 256 * mi::kMaxPerThread, "mi_scale_update: H=%d out of range [1,%d]", H,
                256 * mi::kMaxPerThread);
-  MI_CHECK_ARG(S >= 0, "mi_scale_update: negative S");
+  MI_CHECK_ARG(S >= 0 && ld >= S, "mi_scale_update: need 0 <= S <= ld");
   MI_CHECK_ARG(margin > -100 && margin < 100, "mi_scale_update: margin out of range");
   MI_CHECK_ARG(algo == MI_AMAX_ALGO_MAX || algo == MI_AMAX_ALGO_MOST_RECENT, "mi_scale_update: bad algo %d", algo);
   if (S == 0) return MI_OK;
   float inv_margin_pow = ldexpf(1.0f, -margin);
   hipLaunchKernelGGL(mi::scale_update_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, amax_history, scale,
-                     scale_inv, fp8_max, H, S, inv_margin_pow, algo);
+                     scale_inv, fp8_max, H, ld, inv_margin_pow, algo);
   MI_CHECK_LAUNCH("mi_scale_update launch");
   return MI_OK;
 }

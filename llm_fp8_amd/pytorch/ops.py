@@ -57,12 +57,13 @@ def scale_update(amax_history: torch.Tensor, scale: torch.Tensor, scale_inv: tor
                  fp8_max: torch.Tensor, margin: int = 0, algo: str = "max") -> None:
     """K3, in place on [H, S] history and [S] scale / scale_inv."""
     _dev(amax_history, scale, scale_inv, fp8_max)
-    assert amax_history.dim() == 2 and amax_history.is_contiguous() and amax_history.dtype == torch.float32
+    assert amax_history.dim() == 2 and amax_history.stride(1) == 1 and amax_history.dtype == torch.float32
     H, S = amax_history.shape
     assert scale.numel() == S and scale_inv.numel() == S and fp8_max.numel() == S
     assert scale.is_contiguous() and scale_inv.is_contiguous() and fp8_max.is_contiguous()
     rc = _lib.load().mi_scale_update(amax_history.data_ptr(), scale.data_ptr(), scale_inv.data_ptr(),
-                                     fp8_max.data_ptr(), H, S, margin, 0 if algo == "max" else 1, _stream())
+                                     fp8_max.data_ptr(), H, S, amax_history.stride(0), margin,
+                                     0 if algo == "max" else 1, _stream())
     _lib.check(rc, "mi_scale_update")
 
 

@@ -37,7 +37,7 @@ def test_argument_errors_are_reported_not_thrown():
     lib = _lib.load()
     rc = lib.mi_cast_amax(None, None, None, None, None, 8, 8, 8, 8, 0, None)
     assert rc == -1 and b"non-null" in lib.mi_last_error()
-    rc = lib.mi_scale_update(None, None, None, None, 16, 4, 0, 0, None)
+    rc = lib.mi_scale_update(None, None, None, None, 16, 4, 4, 0, 0, None)
     assert rc == -1
     rc = lib.mi_gemm_fp8(None, None, None, None, None, None, 16, 16, 16, 16, 16, 16, 0, 0, 0, 0, None)
     assert rc == -1 and b"null operand" in lib.mi_last_error()
