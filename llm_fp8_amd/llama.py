@@ -1,0 +1,249 @@
+"""Counterpart of the reference's te_llama.py / te_llama_hybrid.py / te_llama_mxfp8.py on top of
+`llm_fp8_amd.pytorch` (same class names, same monkey-patch, same parameter names), plus the two
+accelerate steps train_fp8.py relies on (`convert_model`, `apply_fp8_autowrap`).
+
+The three reference files differ only in the recipe objects, so one
+file serves all three scenarios:
+
+  scenario   attention region                         MLP region                               reference
+  default    DelayedScaling(HYBRID, 16, "max")        DelayedScaling(E4M3, 16, "max")          te_llama.py:39-40
+  hybrid     DelayedScaling(HYBRID, 16, "max")        same recipe object                       te_llama_hybrid.py:39
+  mxfp8      MXFP8BlockScaling(E4M3)                  same recipe object                       te_llama_mxfp8.py:28-29
+
+No weights, tokenizer or dataset exist offline: configs are hard-coded from the public model cards
+ and models are random-initialised.
+"""
+from __future__ import annotations
+
+import re
+from contextlib import contextmanager
+from typing import Dict, Optional
+
+import torch
+
+from . import pytorch as te
+from .common.recipe import DelayedScaling, Format, MXFP8BlockScaling
+
+LLAMA_CONFIGS: Dict[str, dict] = {
+    "llama-3.2-1b": dict(hidden_size=2048, intermediate_size=8192, num_hidden_layers=16, num_attention_heads=32,
+                         num_key_value_heads=8, head_dim=64, tie_word_embeddings=True),
+    "llama-3.2-3b": dict(hidden_size=3072, intermediate_size=8192, num_hidden_layers=28, num_attention_heads=24,
+                         num_key_value_heads=8, head_dim=128, tie_word_embeddings=True),
+    "llama-3.1-8b": dict(hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32,
+                         num_key_value_heads=8, head_dim=128, tie_word_embeddings=False),
+}
+_ALIASES = {"meta-llama/llama-3.2-1b": "llama-3.2-1b", "meta-llama/llama-3.2-3b": "llama-3.2-3b",
+            "meta-llama/llama-3.1-8b": "llama-3.1-8b", "meta-llama/meta-llama-3.1-8b": "llama-3.1-8b"}
+
+
+def llama_config(name: str, **overrides):
+    """Hard-coded LlamaConfig (there is no config.json offline; train_fp8.py:88 reads one from the hub cache)."""
+    from transformers import LlamaConfig
+    key = name.lower()
+    key = _ALIASES.get(key, key)
+    if key not in LLAMA_CONFIGS:
+        raise KeyError(f"unknown model {name!r}; known: {sorted(LLAMA_CONFIGS)}")
+    kw = dict(vocab_size=128256, rms_norm_eps=1e-5, max_position_embeddings=131072, rope_theta=500000.0,
+              hidden_act="silu", attention_bias=False, mlp_bias=False, initializer_range=0.02, use_cache=False,
+              bos_token_id=128000, eos_token_id=128001)
+    kw.update(LLAMA_CONFIGS[key])
+    kw.update(overrides)
+    cfg = LlamaConfig(**kw)
+    cfg._attn_implementation = "sdpa"  # the reference asks for flash_attention_2 (train_fp8.py:89): absent on ROCm here
+    return cfg
+
+
+def scenario_recipes(scenario: str):
+    """(attention-region recipe, MLP-region recipe) for --fp8_scenario (train_fp8.py:103-116)."""
+    if scenario == "default":
+        return (DelayedScaling(fp8_format=Format.HYBRID, amax_history_len=16, amax_compute_algo="max"),
+                DelayedScaling(fp8_format=Format.E4M3, amax_history_len=16, amax_compute_algo="max"))
+    if scenario == "hybrid":
+        r = DelayedScaling(fp8_format=Format.HYBRID, amax_history_len=16, amax_compute_algo="max")
+        return r, r
+    if scenario == "mxfp8":
+        r = MXFP8BlockScaling(fp8_format=Format.E4M3)
+        return r, r
+    raise ValueError(f"unknown fp8 scenario {scenario!r}")
+
+
+_ROPE_CACHE: Dict[tuple, torch.Tensor] = {}
+
+
+def _rope_table(dim: int, max_len: int, device) -> torch.Tensor:
+    """One shared RoPE angle table per (dim, length, device).  The reference builds one 131072-row table PER
+    LAYER (te_llama.py:65-66); sharing it is value-identical and saves (L-1) x 64 MB of HBM on the 3B model."""
+    key = (dim, max_len, str(device))
+    if key not in _ROPE_CACHE:
+        _ROPE_CACHE[key] = te.attention.RotaryPositionEmbedding(dim)(max_seq_len=max_len).to(device)
+    return _ROPE_CACHE[key]
+
+
+class TELlamaDecoderLayer(torch.nn.Module):
+    """te_llama.py:41-82: MultiheadAttention (+input RMSNorm, GQA, bshd) and LayerNormMLP (RMSNorm, swiglu,
+    TE-default bias=True), each under its own fp8_autocast region, residual adds in between."""
+
+    scenario = "default"
+
+    def __init__(self, config, *args, dropout_rate: float = 0.0, **kwargs):
+        super().__init__()
+        dev = "cuda" if torch.cuda.is_available() else "cpu"
+        self.attn_recipe, self.mlp_recipe = scenario_recipes(self.scenario)
+        self.self_attention = te.MultiheadAttention(
+            hidden_size=config.hidden_size,
+            num_attention_heads=config.num_attention_heads,
+            kv_channels=getattr(config, "head_dim", None) or config.hidden_size // config.num_attention_heads,
+            bias=False,
+            layernorm_epsilon=config.rms_norm_eps,
+            attention_dropout=dropout_rate,
+            fuse_qkv_params=False,
+            normalization="RMSNorm",
+            num_gqa_groups=config.num_key_value_heads,
+            qkv_format="bshd",
+            input_layernorm=True,
+            device=dev,
+        )
+        self.layernorm_mlp = te.LayerNormMLP(
+            hidden_size=config.hidden_size,
+            ffn_hidden_size=config.intermediate_size,
+            normalization="RMSNorm",
+            activation="swiglu",
+            device=dev,
+        )
+        head_dim = getattr(config, "head_dim", None) or config.hidden_size // config.num_attention_heads
+        self.te_rope_emb = _rope_table(head_dim, config.max_position_embeddings, dev)
+
+    def forward(self, hidden_states, attention_mask=None, **kwargs):
+        if not isinstance(hidden_states, torch.Tensor):
+            raise TypeError("hidden_states must be a torch.Tensor")
+        if attention_mask is not None and not isinstance(attention_mask, torch.Tensor):
+            raise TypeError("attention_mask must be a torch.Tensor")
+        fp8 = hidden_states.is_cuda  # FP8 is unconditionally on in the reference layer (te_llama.py:76,79)
+        with te.fp8_autocast(enabled=fp8, fp8_recipe=self.attn_recipe):
+            attn_out = self.self_attention(hidden_states, attention_mask=attention_mask, rotary_pos_emb=self.te_rope_emb)
+        hidden_states = hidden_states + attn_out
+        with te.fp8_autocast(enabled=fp8, fp8_recipe=self.mlp_recipe):
+            ffn_out = self.layernorm_mlp(hidden_states)
+        hidden_states = hidden_states + ffn_out
+        return hidden_states
+
+
+def decoder_layer_cls(scenario: str):
+    scenario_recipes(scenario)  # validate
+    return type(f"TELlamaDecoderLayer_{scenario}", (TELlamaDecoderLayer,), {"scenario": scenario})
+
+
+@contextmanager
+def replace_decoder(te_decoder_cls):
+    """te_llama.py:28-38: swap HF's LlamaDecoderLayer while LlamaForCausalLM is being built."""
+    import transformers
+    mod = transformers.models.llama.modeling_llama
+    original = mod.LlamaDecoderLayer
+    mod.LlamaDecoderLayer = te_decoder_cls
+    try:
+        yield
+    finally:
+        mod.LlamaDecoderLayer = original
+
+
+class TELlamaForCausalLM:
+    """te_llama.py:85-98: HF owns embeddings / final norm / lm_head / loss, our layers own the decoder."""
+
+    def __new__(cls, config, scenario: str = "default"):
+        from transformers.models.llama.modeling_llama import LlamaForCausalLM
+        with replace_decoder(te_decoder_cls=decoder_layer_cls(scenario)):
+            model = LlamaForCausalLM(config)
+        return model
+
+    @classmethod
+    def from_hf_state_dict(cls, hf_state_dict, config, scenario: str = "default", torch_dtype=torch.bfloat16):
+        """Offline counterpart of from_pretrained_local (te_llama.py:100-178): same copy rules, the state dict is
+        handed in instead of being read from a hub snapshot."""
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(torch_dtype)
+        try:
+            model = cls(config, scenario)
+        finally:
+            torch.set_default_dtype(prev)  # the reference never restores it
+        sd = dict(hf_state_dict)
+        replace_params(sd, model.state_dict(), config)
+        model.load_state_dict(sd, strict=False)
+        return model
+
+
+def replace_params(hf_state_dict, te_state_dict, config):
+    """HF -> TE-named parameters, same mapping as te_llama.py:181-239 (q|k|v separate, gate|up stacked)."""
+    prefixes = set()
+    for k in hf_state_dict.keys():
+        m = re.match(r"model\.layers\.\d+\.", k)
+        if m is not None:
+            prefixes.add(m.group())
+    simple = {
+        "input_layernorm.weight": "self_attention.layernorm_qkv.layer_norm_weight",
+        "self_attn.q_proj.weight": "self_attention.layernorm_qkv.query_weight",
+        "self_attn.k_proj.weight": "self_attention.layernorm_qkv.key_weight",
+        "self_attn.v_proj.weight": "self_attention.layernorm_qkv.value_weight",
+        "self_attn.o_proj.weight": "self_attention.proj.weight",
+        "post_attention_layernorm.weight": "layernorm_mlp.layer_norm_weight",
+        "mlp.down_proj.weight": "layernorm_mlp.fc2_weight",
+    }
+    f = config.intermediate_size
+    for p in prefixes:
+        for src, dst in simple.items():
+            if p + src in hf_state_dict:
+                te_state_dict[p + dst].data[:] = hf_state_dict[p + src].data[:]
+        if p + "mlp.gate_proj.weight" in hf_state_dict:
+            te_state_dict[p + "layernorm_mlp.fc1_weight"].data[:f] = hf_state_dict[p + "mlp.gate_proj.weight"].data
+        if p + "mlp.up_proj.weight" in hf_state_dict:
+            te_state_dict[p + "layernorm_mlp.fc1_weight"].data[f:] = hf_state_dict[p + "mlp.up_proj.weight"].data
+    return prefixes
+
+
+# ------------------------------------------------------------------------------------------------------------
+# The two accelerate steps of Accelerator.prepare the reference depends on (accelerator.py:2098-2131,1818-1833).
+# accelerate's own FP8 path needs an installed `transformer_engine` distribution, so the harness does them itself.
+
+def convert_model(model: torch.nn.Module, to_fp8: bool = True, _convert_linear: bool = True) -> int:
+    """nn.Linear -> llm_fp8_amd Linear for every Linear whose dims are multiples of 16
+    (accelerate utils/transformer_engine.py:42-59).  The Parameter objects are re-used, so tied
+    lm_head/embedding weights stay tied.  Unlike accelerate's version this one does
+    not stop at the first non-convertible sibling (its early `return` at :50-51).  Returns #converted."""
+    n = 0
+    for name, child in list(model.named_children()):
+        if isinstance(child, torch.nn.Linear) and to_fp8 and _convert_linear:
+            if child.in_features % 16 or child.out_features % 16:
+                continue
+            new = te.Linear(child.in_features, child.out_features, bias=child.bias is not None,
+                            params_dtype=child.weight.dtype, device=child.weight.device)
+            new.weight = child.weight
+            if child.bias is not None:
+                new.bias = child.bias
+            setattr(model, name, new)
+            n += 1
+        else:
+            n += convert_model(child, to_fp8, _convert_linear)
+    return n
+
+
+def apply_fp8_autowrap(model: torch.nn.Module, fp8_recipe=None, use_during_eval: bool = False):
+    """Wrap `model.forward` in an outer fp8_autocast that is active only in training mode
+    (accelerate utils/transformer_engine.py:118-186)."""
+    recipe = fp8_recipe if fp8_recipe is not None else DelayedScaling()  # accelerate default: HYBRID/1024/most_recent
+    inner = model.forward
+
+    def forward(*args, **kwargs):
+        enabled = (use_during_eval or model.training) and torch.cuda.is_available()
+        with te.fp8_autocast(enabled=enabled, fp8_recipe=recipe):
+            return inner(*args, **kwargs)
+
+    model.forward = forward
+    model._fp8_outer_recipe = recipe
+    return model
+
+
+def outer_recipe_for_scenario(scenario: str):
+    """FP8Handler.create_fp8_kwargs (train_fp8.py:126-165): the OUTER (accelerate) recipe -- used by lm_head."""
+    if scenario == "default":
+        return DelayedScaling(fp8_format=Format.HYBRID, amax_history_len=1024, amax_compute_algo="most_recent")
+    # scenarios mxfp8 / hybrid: E4M3, history 16, "max", margin 0 (never MXFP8 for the outer recipe: Appendix C.9)
+    return DelayedScaling(fp8_format=Format.E4M3, amax_history_len=16, amax_compute_algo="max", margin=0)

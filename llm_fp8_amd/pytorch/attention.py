@@ -1,0 +1,139 @@
+"""Attention pieces with the `transformer_engine.pytorch` surface used at te_llama.py:45-56,65-66,77:
+`MultiheadAttention(...)`(hidden_states, attention_mask=, rotary_pos_emb=) and
+`attention.RotaryPositionEmbedding(dim)(max_seq_len)`.
+
+Only the two projections (`layernorm_qkv`, `proj`) are on the FP8 hot path; the attention core is
+bf16 `scaled_dot_product_attention` on ROCm (the reference's core is bf16 flash-attn, out of scope:
+SURVEY.md 2.3 K11)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from .module import LayerNormLinear, Linear
+
+__all__ = ["RotaryPositionEmbedding", "apply_rotary_pos_emb", "DotProductAttention", "MultiheadAttention"]
+
+
+class RotaryPositionEmbedding(torch.nn.Module):
+    """TE-style RoPE table: forward(max_seq_len) -> [s, 1, 1, dim] float32 of angles (base 10000 by
+    default, as the reference constructs it at te_llama.py:65)."""
+
+    def __init__(self, dim: int, rotary_percent: float = 1.0, seq_len_interpolation_factor=None,
+                 pretrained_max_position_embeddings=None, rotary_base: float = 10000.0):
+        super().__init__()
+        if rotary_percent < 1.0:
+            dim = int(dim * rotary_percent)
+        self.dim = dim
+        self.seq_len_interpolation_factor = seq_len_interpolation_factor
+        inv_freq = 1.0 / (rotary_base ** (torch.arange(0, dim, 2, dtype=torch.float32) / dim))
+        self.register_buffer("inv_freq", inv_freq, persistent=False)
+
+    def forward(self, max_seq_len: int, offset: int = 0) -> torch.Tensor:
+        seq = torch.arange(max_seq_len, device=self.inv_freq.device, dtype=torch.float32) + offset
+        if self.seq_len_interpolation_factor is not None:
+            seq = seq / self.seq_len_interpolation_factor
+        freqs = torch.outer(seq, self.inv_freq)
+        emb = torch.cat((freqs, freqs), dim=-1)
+        return emb.reshape(emb.size(0), 1, 1, emb.size(1))
+
+
+def _rotate_half(x: torch.Tensor) -> torch.Tensor:
+    x1, x2 = x.chunk(2, dim=-1)
+    return torch.cat((-x2, x1), dim=-1)
+
+
+def apply_rotary_pos_emb(t: torch.Tensor, freqs: torch.Tensor, tensor_format: str = "sbhd") -> torch.Tensor:
+    """t: [s,b,h,d] ("sbhd") or [b,s,h,d] ("bshd"); freqs: [s_max,1,1,d_rot] angles."""
+    s = t.shape[0] if tensor_format == "sbhd" else t.shape[1]
+    f = freqs[:s]
+    if tensor_format == "bshd":
+        f = f.transpose(0, 1)  # [1, s, 1, d]
+    cos, sin = torch.cos(f).to(t.dtype), torch.sin(f).to(t.dtype)
+    rot = f.shape[-1]
+    tr, tp = t[..., :rot], t[..., rot:]
+    out = tr * cos + _rotate_half(tr) * sin
+    return out if tp.shape[-1] == 0 else torch.cat((out, tp), dim=-1)
+
+
+class DotProductAttention(torch.nn.Module):
+    """bf16 attention core.  q [b,s,h,d], k/v [b,s,g,d] (bshd) -> [b,s,h*d]."""
+
+    def __init__(self, num_attention_heads: int, kv_channels: int, num_gqa_groups: Optional[int] = None,
+                 attention_dropout: float = 0.0, attn_mask_type: str = "causal", qkv_format: str = "bshd", **_ignored):
+        super().__init__()
+        self.h, self.d = num_attention_heads, kv_channels
+        self.g = num_gqa_groups or num_attention_heads
+        self.p, self.attn_mask_type, self.qkv_format = attention_dropout, attn_mask_type, qkv_format
+
+    def forward(self, q, k, v, attention_mask=None):
+        if self.qkv_format == "sbhd":
+            q, k, v = (t.transpose(0, 1) for t in (q, k, v))
+        q, k, v = (t.transpose(1, 2) for t in (q, k, v))  # [b, h, s, d]
+        causal = self.attn_mask_type in ("causal", "padding_causal")
+        mask = None
+        if not causal and attention_mask is not None:
+            mask = ~attention_mask if attention_mask.dtype == torch.bool else attention_mask  # TE: True = masked out
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=self.p if self.training else 0.0,
+                                           is_causal=causal, enable_gqa=(self.g != self.h))
+        o = o.transpose(1, 2)  # [b, s, h, d]
+        if self.qkv_format == "sbhd":
+            o = o.transpose(0, 1)
+        return o.reshape(*o.shape[:2], self.h * self.d)
+
+
+class MultiheadAttention(torch.nn.Module):
+    """`layernorm_qkv` (LayerNormLinear with query_/key_/value_weight) -> RoPE -> attention -> `proj` (Linear).
+
+    Arguments follow te.pytorch.MultiheadAttention as called at te_llama.py:45-56.  The default mask type is
+    causal and, as in TE, a padding `attention_mask` passed with the causal type is ignored
+    (SURVEY.md 8a row a5)."""
+
+    def __init__(self, hidden_size: int, num_attention_heads: int, kv_channels: Optional[int] = None,
+                 attention_dropout: float = 0.1, layernorm_epsilon: float = 1e-5, init_method=None,
+                 output_layer_init_method=None, attn_mask_type: str = "causal", num_gqa_groups: Optional[int] = None,
+                 input_layernorm: bool = False, attention_type: str = "self", fuse_qkv_params: bool = False,
+                 zero_centered_gamma: bool = False, qkv_weight_interleaved: bool = True, bias: bool = True,
+                 normalization: str = "LayerNorm", qkv_format: str = "sbhd", params_dtype=None, device="cuda",
+                 **_ignored):
+        super().__init__()
+        assert attention_type == "self", "only self-attention is on the reference path"
+        assert qkv_format in ("sbhd", "bshd")
+        self.hidden_size, self.h = hidden_size, num_attention_heads
+        self.d = kv_channels or hidden_size // num_attention_heads
+        self.g = num_gqa_groups or num_attention_heads
+        self.qkv_format, self.input_layernorm = qkv_format, input_layernorm
+        q_out, kv_out = self.h * self.d, self.g * self.d
+        self.split = (q_out, kv_out, kv_out)
+        if fuse_qkv_params:
+            psplit = None
+        else:
+            psplit = {"query_": q_out, "key_": kv_out, "value_": kv_out}
+        if input_layernorm:
+            self.layernorm_qkv = LayerNormLinear(hidden_size, sum(self.split), eps=layernorm_epsilon, bias=bias,
+                                                 normalization=normalization, parameters_split=psplit,
+                                                 params_dtype=params_dtype, device=device,
+                                                 zero_centered_gamma=zero_centered_gamma, init_method=init_method)
+        else:
+            self.qkv = Linear(hidden_size, sum(self.split), bias=bias, params_dtype=params_dtype, device=device,
+                              init_method=init_method)
+        self.core_attention = DotProductAttention(self.h, self.d, self.g, attention_dropout, attn_mask_type, qkv_format)
+        self.proj = Linear(q_out, hidden_size, bias=bias, params_dtype=params_dtype, device=device,
+                           init_method=output_layer_init_method or init_method)
+
+    def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                rotary_pos_emb=None, **_ignored) -> torch.Tensor:
+        qkv = self.layernorm_qkv(hidden_states) if self.input_layernorm else self.qkv(hidden_states)
+        q, k, v = torch.split(qkv, self.split, dim=-1)
+        a, b = qkv.shape[0], qkv.shape[1]
+        q = q.reshape(a, b, self.h, self.d)
+        k = k.reshape(a, b, self.g, self.d)
+        v = v.reshape(a, b, self.g, self.d)
+        if rotary_pos_emb is not None:
+            fq, fk = rotary_pos_emb if isinstance(rotary_pos_emb, (tuple, list)) else (rotary_pos_emb, rotary_pos_emb)
+            q = apply_rotary_pos_emb(q, fq, self.qkv_format)
+            k = apply_rotary_pos_emb(k, fk, self.qkv_format)
+        ctx = self.core_attention(q, k, v, attention_mask)
+        return self.proj(ctx)

@@ -1,0 +1,376 @@
+"""FP8 modules with the `transformer_engine.pytorch` surface the reference consumes:
+`Linear` (accelerate utils/transformer_engine.py:52-59), `LayerNormLinear` / `LayerNormMLP`
+(te_llama.py:45-63 via MultiheadAttention / LayerNormMLP), same parameter names as
+`replace_params` writes (te_llama.py:194-238).
+
+Every GEMM site is ONE autograd Function (`_FP8LinearFn`) whose forward/backward run only HIP kernels
+from libmi_fp8.so:
+
+  fwd:  x  --cast+T+amax-->  x8, x8T     w  --cast+T+amax-->  w8, w8T      y  = gemm(x8, w8)  (+bias)
+  bwd:  dy --cast+T+amax-->  g8, g8T     dx = gemm(g8, w8T)                dw = gemm(g8T, x8T)
+
+(SURVEY.md 3.4).  Weights stay bf16 `nn.Parameter`s; nothing here falls back to PyTorch matmuls when
+FP8 is enabled.  Outside `fp8_autocast` (or with enabled=False) the modules are plain bf16 layers.
+"""
+from __future__ import annotations
+
+import io
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from ..common.recipe import DelayedScaling, Format, MXFP8BlockScaling, Recipe, fmt_codes
+from . import ops
+from .fp8 import FP8GlobalStateManager, ModuleMeta
+
+__all__ = ["Linear", "LayerNormLinear", "LayerNormMLP", "LayerNorm", "RMSNorm"]
+
+
+def _as_bf16_2d(t: torch.Tensor) -> torch.Tensor:
+    t2 = t.reshape(-1, t.shape[-1])
+    if t2.dtype != torch.bfloat16:
+        t2 = t2.to(torch.bfloat16)
+    return t2.contiguous()
+
+
+class _GemmSpec:
+    """Everything non-tensor a GEMM site needs: recipe, meta windows, slot base, update trigger."""
+    __slots__ = ("recipe", "meta_fwd", "meta_bwd", "g", "fmt_fwd", "fmt_bwd", "trigger_bwd_update", "training")
+
+    def __init__(self, recipe, meta_fwd, meta_bwd, g, trigger_bwd_update, training):
+        self.recipe, self.meta_fwd, self.meta_bwd, self.g = recipe, meta_fwd, meta_bwd, g
+        self.fmt_fwd, self.fmt_bwd = fmt_codes(recipe.fp8_format)
+        self.trigger_bwd_update = trigger_bwd_update
+        self.training = training
+
+
+class _FP8LinearFn(torch.autograd.Function):
+    """y[M, sum N_i] = x[M,K] . cat(W_i)[N,K]^T (+ bias), FP8 operands, bf16 result."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, bias: Optional[torch.Tensor], spec: _GemmSpec, *weights: torch.Tensor):
+        x2 = _as_bf16_2d(x)
+        M, K = x2.shape
+        if M % 8 or K % 16:
+            raise RuntimeError(f"FP8 Linear needs tokens % 8 == 0 and in_features % 16 == 0, got {M} x {K}")
+        ns = [w.shape[0] for w in weights]
+        N = sum(ns)
+        dev = x2.device
+        # (forward runs in no-grad mode; needs_input_grad is all-False when grad was disabled at apply time)
+        need_dgrad = bool(ctx.needs_input_grad[0])
+        need_wgrad = any(ctx.needs_input_grad[3:])
+        bias_bf16 = None if bias is None else bias.to(torch.bfloat16).contiguous()
+        if spec.recipe.mxfp8():
+            wcat = weights[0] if len(weights) == 1 else torch.cat(list(weights), 0)
+            wcat = wcat if wcat.dtype == torch.bfloat16 else wcat.to(torch.bfloat16)
+            x8, xs, xt8, xts = ops.mxfp8_quantize(x2, spec.fmt_fwd, rowwise=True, colwise=need_wgrad)
+            w8, ws, wt8, wts = ops.mxfp8_quantize(wcat.contiguous(), spec.fmt_fwd, rowwise=True, colwise=need_dgrad)
+            y = ops.gemm_mxfp8(x8, xs, w8, ws, spec.fmt_fwd, spec.fmt_fwd, bias=bias_bf16)
+            ctx.saved_fp8 = (xt8, xts, wt8, wts, None)
+        else:
+            mf, g = spec.meta_fwd, spec.g
+            x8, x8t = ops.cast_amax(x2, mf.scale(3 * g), mf.amax(3 * g), spec.fmt_fwd, want_t=need_wgrad)
+            w8 = torch.empty((N, K), dtype=torch.uint8, device=dev)
+            w8t = torch.empty((K, N), dtype=torch.uint8, device=dev) if need_dgrad else None
+            r = 0
+            for w, n in zip(weights, ns):
+                wb = w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)
+                ops.cast_amax(wb.contiguous(), mf.scale(3 * g + 1), mf.amax(3 * g + 1), spec.fmt_fwd,
+                              y=w8[r:r + n], yT=None if w8t is None else w8t[:, r:r + n], want_t=need_dgrad)
+                r += n
+            y = ops.gemm_fp8(x8, w8, mf.scale_inv(3 * g), mf.scale_inv(3 * g + 1), spec.fmt_fwd, spec.fmt_fwd,
+                             bias=bias_bf16)
+            # scale_inv as of quantisation time: the arena is updated at autocast exit, before backward
+            sinv = mf.scale_inv_snapshot() if (need_wgrad or need_dgrad) else None
+            ctx.saved_fp8 = (x8t, None, w8t, None, sinv)
+        ctx.spec, ctx.ns, ctx.x_shape, ctx.x_dtype = spec, ns, x.shape, x.dtype
+        ctx.w_dtypes = [w.dtype for w in weights]
+        ctx.has_bias, ctx.bias_dtype = bias is not None, (None if bias is None else bias.dtype)
+        ctx.need_wgrad, ctx.need_dgrad = need_wgrad, need_dgrad
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy: torch.Tensor):
+        spec = ctx.spec
+        g2 = _as_bf16_2d(dy)
+        M, N = g2.shape
+        xt8, xts, wt8, wts, sinv = ctx.saved_fp8
+        ctx.saved_fp8 = None
+        dx = dw = None
+        if spec.recipe.mxfp8():
+            g8, gs, gt8, gts = ops.mxfp8_quantize(g2, spec.fmt_bwd, rowwise=ctx.need_dgrad, colwise=ctx.need_wgrad)
+            if ctx.need_dgrad:
+                dx = ops.gemm_mxfp8(g8, gs, wt8, wts, spec.fmt_bwd, spec.fmt_fwd)
+            if ctx.need_wgrad:
+                dw = ops.gemm_mxfp8(gt8, gts, xt8, xts, spec.fmt_bwd, spec.fmt_fwd)
+        else:
+            mb, g = spec.meta_bwd, spec.g
+            g8, g8t = ops.cast_amax(g2, mb.scale(2 * g), mb.amax(2 * g), spec.fmt_bwd,
+                                    want_y=ctx.need_dgrad, want_t=ctx.need_wgrad)
+            sig = mb.scale_inv(2 * g)
+            if ctx.need_dgrad:
+                dx = ops.gemm_fp8(g8, wt8, sig, sinv[3 * g + 1:3 * g + 2], spec.fmt_bwd, spec.fmt_fwd)
+            if ctx.need_wgrad:
+                dw = ops.gemm_fp8(g8t, xt8, sig, sinv[3 * g:3 * g + 1], spec.fmt_bwd, spec.fmt_fwd)
+        db = None
+        if ctx.has_bias:
+            db = g2.sum(0, dtype=torch.float32).to(ctx.bias_dtype)
+        if spec.trigger_bwd_update:
+            # this GEMM belongs to the first FP8 module of the outermost autocast: its backward is the last
+            FP8GlobalStateManager.reduce_and_update_fp8_tensors(forward=False)
+        if dx is not None:
+            dx = dx.view(ctx.x_shape).to(ctx.x_dtype)
+        dws: List[Optional[torch.Tensor]] = [None] * len(ctx.ns)
+        if dw is not None:
+            parts = torch.split(dw, ctx.ns, dim=0)
+            dws = [p if p.dtype == dt else p.to(dt) for p, dt in zip(parts, ctx.w_dtypes)]
+        return (dx, db, None, *dws)
+
+
+class _FP8Module(torch.nn.Module):
+    """Shared FP8 bookkeeping: lazily allocated meta windows, `_extra_state` (TE serialises its FP8
+    metadata there; it ends up in `save_pretrained`, train_fp8.py:668-669)."""
+
+    num_gemms = 1
+
+    def __init__(self):
+        super().__init__()
+        self._meta_fwd: Optional[ModuleMeta] = None
+        self._meta_bwd: Optional[ModuleMeta] = None
+        self._meta_key = None
+        self._pending_state = None
+
+    def _prepare(self, device) -> Optional[Tuple[Recipe, Optional[ModuleMeta], Optional[ModuleMeta], bool]]:
+        """Called at the top of forward.  None -> run the plain bf16 path."""
+        if not FP8GlobalStateManager.is_fp8_enabled():
+            return None
+        recipe = FP8GlobalStateManager.get_fp8_recipe()
+        first = FP8GlobalStateManager.is_first_fp8_module()
+        if recipe.mxfp8():
+            return recipe, None, None, first
+        key = (recipe.fp8_format, recipe.amax_history_len, recipe.amax_compute_algo, recipe.margin, str(device))
+        if self._meta_key != key:
+            fa = FP8GlobalStateManager.arena(recipe, True, device)
+            ba = FP8GlobalStateManager.arena(recipe, False, device)
+            self._meta_fwd = ModuleMeta(fa, fa.alloc(3 * self.num_gemms), 3 * self.num_gemms)
+            self._meta_bwd = ModuleMeta(ba, ba.alloc(2 * self.num_gemms), 2 * self.num_gemms)
+            self._meta_key = key
+            if self._pending_state is not None:
+                self._meta_fwd.load_state(self._pending_state["fwd"])
+                self._meta_bwd.load_state(self._pending_state["bwd"])
+                self._pending_state = None
+        else:  # arenas may carry a new group / reduce flag
+            FP8GlobalStateManager.arena(recipe, True, device)
+            FP8GlobalStateManager.arena(recipe, False, device)
+        return recipe, self._meta_fwd, self._meta_bwd, first
+
+    def get_extra_state(self):
+        if self._meta_fwd is None:
+            return torch.empty(0, dtype=torch.uint8)
+        buf = io.BytesIO()
+        to_cpu = lambda d: {k: v.cpu() for k, v in d.items()}
+        torch.save({"fwd": to_cpu(self._meta_fwd.state()), "bwd": to_cpu(self._meta_bwd.state())}, buf)
+        return torch.frombuffer(bytearray(buf.getvalue()), dtype=torch.uint8)
+
+    def set_extra_state(self, state):
+        if state is None or (isinstance(state, torch.Tensor) and state.numel() == 0):
+            return
+        st = torch.load(io.BytesIO(state.cpu().numpy().tobytes()), weights_only=True)
+        if self._meta_fwd is not None:
+            self._meta_fwd.load_state(st["fwd"])
+            self._meta_bwd.load_state(st["bwd"])
+        else:
+            self._pending_state = st
+
+
+def _rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, zero_centered_gamma: bool = False) -> torch.Tensor:
+    w = weight + 1 if zero_centered_gamma else weight
+    return F.rms_norm(x, (x.shape[-1],), w, eps)
+
+
+def _layernorm(x, weight, bias, eps, zero_centered_gamma=False):
+    w = weight + 1 if zero_centered_gamma else weight
+    return F.layer_norm(x, (x.shape[-1],), w, bias, eps)
+
+
+class RMSNorm(torch.nn.Module):
+    def __init__(self, hidden_size: int, eps: float = 1e-5, params_dtype=None, device="cuda", zero_centered_gamma=False):
+        super().__init__()
+        self.eps, self.zero_centered_gamma = eps, zero_centered_gamma
+        self.weight = torch.nn.Parameter(torch.ones(hidden_size, dtype=params_dtype or torch.get_default_dtype(), device=device))
+
+    def forward(self, x):
+        return _rmsnorm(x, self.weight, self.eps, self.zero_centered_gamma)
+
+
+class LayerNorm(torch.nn.Module):
+    """Present for `isinstance` checks in accelerate (utils/transformer_engine.py:109) and as a plain LN."""
+
+    def __init__(self, hidden_size: int, eps: float = 1e-5, params_dtype=None, device="cuda", zero_centered_gamma=False):
+        super().__init__()
+        self.eps, self.zero_centered_gamma = eps, zero_centered_gamma
+        dt = params_dtype or torch.get_default_dtype()
+        self.weight = torch.nn.Parameter(torch.ones(hidden_size, dtype=dt, device=device))
+        self.bias = torch.nn.Parameter(torch.zeros(hidden_size, dtype=dt, device=device))
+
+    def forward(self, x):
+        return _layernorm(x, self.weight, self.bias, self.eps, self.zero_centered_gamma)
+
+
+def _init_weight(shape, dtype, device, init_method=None):
+    w = torch.empty(shape, dtype=dtype, device=device)
+    if init_method is not None:
+        init_method(w)
+    else:
+        torch.nn.init.normal_(w, mean=0.0, std=0.023)  # TE default init_method_normal(0.023)
+    return torch.nn.Parameter(w)
+
+
+class Linear(_FP8Module):
+    """Drop-in for `te.pytorch.Linear(in_features, out_features, bias=..., params_dtype=...)`."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, params_dtype=None, device="cuda",
+                 init_method=None, **_ignored):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        dt = params_dtype or torch.get_default_dtype()
+        self.weight = _init_weight((out_features, in_features), dt, device, init_method)
+        self.bias = torch.nn.Parameter(torch.zeros(out_features, dtype=dt, device=device)) if bias else None
+        self.use_bias = bias
+
+    def forward(self, inp: torch.Tensor, is_first_microbatch=None) -> torch.Tensor:
+        st = self._prepare(inp.device)
+        if st is None:
+            return F.linear(inp, self.weight.to(inp.dtype), None if self.bias is None else self.bias.to(inp.dtype))
+        recipe, mf, mb, first = st
+        spec = _GemmSpec(recipe, mf, mb, 0, first, self.training)
+        return _FP8LinearFn.apply(inp, self.bias, spec, self.weight)
+
+    def extra_repr(self):
+        return f"in_features={self.in_features}, out_features={self.out_features}, bias={self.use_bias}"
+
+
+class LayerNormLinear(_FP8Module):
+    """Norm -> FP8 Linear.  With `parameters_split` the weight is kept as separate Parameters
+    (`query_weight`, `key_weight`, `value_weight`, te_llama.py:200-217) that form ONE GEMM operand and
+    share ONE weight amax/scale slot (SURVEY.md Appendix A "Fused-QKV")."""
+
+    def __init__(self, in_features: int, out_features: int, eps: float = 1e-5, bias: bool = True,
+                 normalization: str = "LayerNorm", parameters_split=None, params_dtype=None, device="cuda",
+                 zero_centered_gamma: bool = False, init_method=None, return_layernorm_output: bool = False, **_ignored):
+        super().__init__()
+        assert normalization in ("LayerNorm", "RMSNorm")
+        self.in_features, self.out_features, self.eps = in_features, out_features, eps
+        self.normalization, self.zero_centered_gamma = normalization, zero_centered_gamma
+        self.return_layernorm_output = return_layernorm_output
+        dt = params_dtype or torch.get_default_dtype()
+        self.layer_norm_weight = torch.nn.Parameter(
+            torch.zeros(in_features, dtype=dt, device=device) if zero_centered_gamma else torch.ones(in_features, dtype=dt, device=device))
+        self.layer_norm_bias = (torch.nn.Parameter(torch.zeros(in_features, dtype=dt, device=device))
+                                if normalization == "LayerNorm" else None)
+        if parameters_split is None:
+            self.weight_names, sizes = ["weight"], [out_features]
+            self.bias_names = ["bias"]
+        else:
+            if isinstance(parameters_split, dict):
+                names, sizes = list(parameters_split.keys()), list(parameters_split.values())
+            else:
+                names = list(parameters_split)
+                assert out_features % len(names) == 0
+                sizes = [out_features // len(names)] * len(names)
+            assert sum(sizes) == out_features
+            self.weight_names = [f"{n.rstrip('_')}_weight" for n in names]
+            self.bias_names = [f"{n.rstrip('_')}_bias" for n in names]
+        self.split_sizes = sizes
+        for n, sz in zip(self.weight_names, sizes):
+            setattr(self, n, _init_weight((sz, in_features), dt, device, init_method))
+        self.use_bias = bias
+        for n, sz in zip(self.bias_names, sizes):
+            if bias:
+                setattr(self, n, torch.nn.Parameter(torch.zeros(sz, dtype=dt, device=device)))
+            else:
+                setattr(self, n, None)
+
+    def _weights(self):
+        return [getattr(self, n) for n in self.weight_names]
+
+    def _bias(self):
+        if not self.use_bias:
+            return None
+        bs = [getattr(self, n) for n in self.bias_names]
+        return bs[0] if len(bs) == 1 else torch.cat(bs, 0)
+
+    def _norm(self, x):
+        if self.normalization == "RMSNorm":
+            return _rmsnorm(x, self.layer_norm_weight, self.eps, self.zero_centered_gamma)
+        return _layernorm(x, self.layer_norm_weight, self.layer_norm_bias, self.eps, self.zero_centered_gamma)
+
+    def forward(self, inp: torch.Tensor, is_first_microbatch=None):
+        st = self._prepare(inp.device)
+        ln = self._norm(inp)
+        ws, b = self._weights(), self._bias()
+        if st is None:
+            w = ws[0] if len(ws) == 1 else torch.cat(ws, 0)
+            out = F.linear(ln, w.to(ln.dtype), None if b is None else b.to(ln.dtype))
+        else:
+            recipe, mf, mb, first = st
+            out = _FP8LinearFn.apply(ln, b, _GemmSpec(recipe, mf, mb, 0, first, self.training), *ws)
+        return (out, ln) if self.return_layernorm_output else out
+
+
+def _swiglu(a: torch.Tensor) -> torch.Tensor:
+    f = a.shape[-1] // 2
+    return F.silu(a[..., :f]) * a[..., f:]
+
+
+_ACTS = {
+    "swiglu": (_swiglu, 2), "gelu": (lambda a: F.gelu(a, approximate="tanh"), 1), "relu": (F.relu, 1),
+    "geglu": (lambda a: F.gelu(a[..., :a.shape[-1] // 2], approximate="tanh") * a[..., a.shape[-1] // 2:], 2),
+    "silu": (F.silu, 1),
+}
+
+
+class LayerNormMLP(_FP8Module):
+    """Norm -> fc1 (FP8) -> activation -> fc2 (FP8); parameters `layer_norm_weight`, `fc1_weight`
+    [gate|up stacked: 2*ffn, hidden], `fc1_bias`, `fc2_weight`, `fc2_bias` (te_llama.py:58-63,219-238).
+    `bias=True` is TE's default and the reference does not override it."""
+
+    num_gemms = 2
+
+    def __init__(self, hidden_size: int, ffn_hidden_size: int, eps: float = 1e-5, bias: bool = True,
+                 normalization: str = "LayerNorm", activation: str = "gelu", params_dtype=None, device="cuda",
+                 zero_centered_gamma: bool = False, init_method=None, output_layer_init_method=None, **_ignored):
+        super().__init__()
+        assert normalization in ("LayerNorm", "RMSNorm") and activation in _ACTS
+        self.hidden_size, self.ffn_hidden_size, self.eps = hidden_size, ffn_hidden_size, eps
+        self.normalization, self.activation, self.zero_centered_gamma = normalization, activation, zero_centered_gamma
+        self.act_fn, mult = _ACTS[activation]
+        dt = params_dtype or torch.get_default_dtype()
+        self.layer_norm_weight = torch.nn.Parameter(
+            torch.zeros(hidden_size, dtype=dt, device=device) if zero_centered_gamma else torch.ones(hidden_size, dtype=dt, device=device))
+        self.layer_norm_bias = (torch.nn.Parameter(torch.zeros(hidden_size, dtype=dt, device=device))
+                                if normalization == "LayerNorm" else None)
+        self.fc1_weight = _init_weight((mult * ffn_hidden_size, hidden_size), dt, device, init_method)
+        self.fc2_weight = _init_weight((hidden_size, ffn_hidden_size), dt, device, output_layer_init_method or init_method)
+        self.use_bias = bias
+        self.fc1_bias = torch.nn.Parameter(torch.zeros(mult * ffn_hidden_size, dtype=dt, device=device)) if bias else None
+        self.fc2_bias = torch.nn.Parameter(torch.zeros(hidden_size, dtype=dt, device=device)) if bias else None
+
+    def _norm(self, x):
+        if self.normalization == "RMSNorm":
+            return _rmsnorm(x, self.layer_norm_weight, self.eps, self.zero_centered_gamma)
+        return _layernorm(x, self.layer_norm_weight, self.layer_norm_bias, self.eps, self.zero_centered_gamma)
+
+    def forward(self, inp: torch.Tensor, is_first_microbatch=None) -> torch.Tensor:
+        st = self._prepare(inp.device)
+        ln = self._norm(inp)
+        if st is None:
+            h = F.linear(ln, self.fc1_weight.to(ln.dtype), None if self.fc1_bias is None else self.fc1_bias.to(ln.dtype))
+            return F.linear(self.act_fn(h), self.fc2_weight.to(ln.dtype),
+                            None if self.fc2_bias is None else self.fc2_bias.to(ln.dtype))
+        recipe, mf, mb, first = st
+        # fc1's backward is the last FP8 op of this module's backward -> it carries the update trigger
+        h = _FP8LinearFn.apply(ln, self.fc1_bias, _GemmSpec(recipe, mf, mb, 0, first, self.training), self.fc1_weight)
+        a = self.act_fn(h)
+        return _FP8LinearFn.apply(a, self.fc2_bias, _GemmSpec(recipe, mf, mb, 1, False, self.training), self.fc2_weight)

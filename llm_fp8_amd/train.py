@@ -1,0 +1,205 @@
+"""Counterpart of the reference's training harness on top of llm_fp8_amd: same flag names as
+train_fp8.py:684-788 / config.py, same model-selection rules (ModelManager, train_fp8.py:83-124), same
+prepare order (convert -> bf16 autocast -> outer fp8 autowrap; accelerate accelerator.py:2098-2131,
+1818-1833) and the same optimiser step order (train_fp8.py:270-291).  Data and weights are synthetic /
+random-init: the hub dataset, tokenizer and checkpoints are unreachable offline.
+
+Multi-GPU follows train_multi_gpu.py: one process per GPU, `nccl` (= RCCL over xGMI) backend, FSDP
+FULL_SHARD around each decoder layer (`:381-460`) or DDP (`:355-378`).
+"""
+from __future__ import annotations
+
+import argparse
+import functools
+import json
+import math
+import os
+import time
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+
+from . import llama
+from .pytorch.fp8 import FP8GlobalStateManager
+
+
+@dataclass
+class TrainingConfig:
+    """Field names follow config.py:5-47 / train_fp8.py argparse."""
+    model_name: str = "meta-llama/Llama-3.2-3B"
+    batch_size: int = 16
+    max_seq_length: int = 512
+    mixed_precision: str = "fp8"          # "bf16" | "fp8"
+    fp8_scenario: str = "default"         # "default" | "hybrid" | "mxfp8"
+    use_te: bool = True
+    learning_rate: float = 1.41e-5
+    num_warmup_steps: int = 100
+    num_training_steps: int = 1000
+    gradient_accumulation_steps: int = 1
+    max_grad_norm: float = 1.0
+    sharding_mode: str = "auto"           # "auto" | "ddp" | "fsdp_full" | "none"
+    seed: int = 42
+    num_hidden_layers: Optional[int] = None  # override for small tests only
+    vocab_size: Optional[int] = None
+
+
+def create_model(cfg: TrainingConfig, device) -> torch.nn.Module:
+    """ModelManager.create_model (train_fp8.py:83-124): TE-style wrapper when --use_te, else plain HF bf16."""
+    from transformers.models.llama.modeling_llama import LlamaForCausalLM
+    over = {}
+    if cfg.num_hidden_layers is not None:
+        over["num_hidden_layers"] = cfg.num_hidden_layers
+    if cfg.vocab_size is not None:
+        over["vocab_size"] = cfg.vocab_size
+    config = llama.llama_config(cfg.model_name, **over)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device(device):
+            if cfg.use_te:
+                model = llama.TELlamaForCausalLM(config, cfg.fp8_scenario)
+            else:
+                model = LlamaForCausalLM(config)
+    finally:
+        torch.set_default_dtype(prev)
+    model.to(device)
+    model.config.use_cache = False
+    return model
+
+
+def prepare_model(model: torch.nn.Module, cfg: TrainingConfig) -> torch.nn.Module:
+    """Accelerator.prepare's model steps for mixed_precision in {bf16, fp8}."""
+    if cfg.mixed_precision == "fp8":
+        llama.convert_model(model)  # lm_head with --use_te; every q/k/v/o/gate/up/down/lm_head without it
+        recipe = llama.outer_recipe_for_scenario(cfg.fp8_scenario) if cfg.use_te else None
+        llama.apply_fp8_autowrap(model, recipe)
+    inner = model.forward
+
+    def forward(*args, **kwargs):
+        with torch.autocast(device_type="cuda" if torch.cuda.is_available() else "cpu", dtype=torch.bfloat16):
+            return inner(*args, **kwargs)
+
+    model.forward = forward
+    return model
+
+
+def wrap_distributed(model: torch.nn.Module, cfg: TrainingConfig, device) -> torch.nn.Module:
+    """DistributedWrapper (train_multi_gpu.py:328-510)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or cfg.sharding_mode == "none":
+        return model
+    mode = cfg.sharding_mode
+    if mode == "auto":
+        mode = "fsdp_full"  # DistributedConfig: auto -> FSDP when more than one GPU (train_multi_gpu.py:81-146)
+    if mode == "ddp":
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        return DDP(model, device_ids=[device.index] if device.type == "cuda" else None, gradient_as_bucket_view=True)
+    if mode == "fsdp_full":
+        from torch.distributed.fsdp import BackwardPrefetch, FullyShardedDataParallel as FSDP, MixedPrecision, ShardingStrategy
+        from torch.distributed.fsdp.wrap import transformer_auto_wrap_policy
+        from transformers.models.llama.modeling_llama import LlamaDecoderLayer
+        layer_cls = {llama.TELlamaDecoderLayer, LlamaDecoderLayer}
+        policy = functools.partial(transformer_auto_wrap_policy, transformer_layer_cls=layer_cls)
+        mp = MixedPrecision(param_dtype=torch.bfloat16, reduce_dtype=torch.bfloat16, buffer_dtype=torch.bfloat16)
+        return FSDP(model, sharding_strategy=ShardingStrategy.FULL_SHARD, auto_wrap_policy=policy, mixed_precision=mp,
+                    backward_prefetch=BackwardPrefetch.BACKWARD_PRE, forward_prefetch=True, limit_all_gathers=True,
+                    use_orig_params=True, sync_module_states=True,
+                    device_id=device if device.type == "cuda" else None)
+    raise ValueError(f"unsupported sharding_mode {cfg.sharding_mode!r}")
+
+
+def create_optimizer(model, cfg: TrainingConfig):
+    """AdamW(fused=True) + linear warmup/decay (train_fp8.py:200-210)."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    fused = all(p.is_cuda for p in params)
+    opt = torch.optim.AdamW(params, lr=cfg.learning_rate, fused=fused)
+
+    def lr_lambda(step):
+        if step < cfg.num_warmup_steps:
+            return float(step) / float(max(1, cfg.num_warmup_steps))
+        return max(0.0, float(cfg.num_training_steps - step) / float(max(1, cfg.num_training_steps - cfg.num_warmup_steps)))
+
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda)
+    return opt, sched
+
+
+def synthetic_batch(cfg: TrainingConfig, vocab_size: int, device, generator=None):
+    """What DataCollatorForLanguageModeling(mlm=False) yields without padding (data.py:59-63): labels = input_ids."""
+    ids = torch.randint(0, vocab_size, (cfg.batch_size, cfg.max_seq_length), device=device, generator=generator)
+    return {"input_ids": ids, "attention_mask": torch.ones_like(ids), "labels": ids.clone()}
+
+
+def train_step(model, batch, optimizer, scheduler, cfg: TrainingConfig):
+    """One iteration of Trainer._train_epoch (train_fp8.py:276-291).  Returns the loss tensor (no host sync)."""
+    outputs = model(**batch)
+    loss = outputs.loss
+    loss.backward()
+    if hasattr(model, "clip_grad_norm_"):
+        model.clip_grad_norm_(cfg.max_grad_norm)  # FSDP
+    else:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.max_grad_norm)
+    optimizer.step()
+    scheduler.step()
+    optimizer.zero_grad()
+    return loss
+
+
+def setup_distributed():
+    """setup_distributed (train_multi_gpu.py:969-1006): env rendezvous, nccl (= RCCL) backend, one device per rank."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+    else:
+        device = torch.device("cpu")
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl" if device.type == "cuda" else "gloo", rank=rank, world_size=world,
+                                device_id=device if device.type == "cuda" else None)
+    return rank, local, world, device
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="FP8 fine-tuning harness (synthetic data) on llm_fp8_amd")
+    ap.add_argument("--model_name", default="meta-llama/Llama-3.2-3B")
+    ap.add_argument("--batch_size", type=int, default=16)
+    ap.add_argument("--max_seq_length", type=int, default=512)
+    ap.add_argument("--mixed_precision", choices=["bf16", "fp8"], default="fp8")
+    ap.add_argument("--fp8_scenario", choices=["default", "hybrid", "mxfp8"], default="default")
+    ap.add_argument("--use_te", action="store_true")
+    ap.add_argument("--sharding_mode", default="auto")
+    ap.add_argument("--num_steps", type=int, default=10)
+    ap.add_argument("--learning_rate", type=float, default=1.41e-5)
+    ap.add_argument("--num_hidden_layers", type=int, default=None)
+    a = ap.parse_args(argv)
+    cfg = TrainingConfig(model_name=a.model_name, batch_size=a.batch_size, max_seq_length=a.max_seq_length,
+                         mixed_precision=a.mixed_precision, fp8_scenario=a.fp8_scenario, use_te=a.use_te,
+                         sharding_mode=a.sharding_mode, learning_rate=a.learning_rate,
+                         num_hidden_layers=a.num_hidden_layers)
+    rank, local, world, device = setup_distributed()
+    torch.manual_seed(cfg.seed + rank)
+    model = prepare_model(create_model(cfg, device), cfg)
+    vocab = model.config.vocab_size
+    model = wrap_distributed(model, cfg, device)
+    opt, sched = create_optimizer(model, cfg)
+    model.train()
+    for step in range(a.num_steps):
+        t0 = time.perf_counter()
+        loss = train_step(model, synthetic_batch(cfg, vocab, device), opt, sched, cfg)
+        lv = loss.item()
+        if not math.isfinite(lv):
+            print("Non-finite loss detected, stopping training.")
+            break
+        dt = time.perf_counter() - t0
+        if rank == 0:
+            toks = cfg.batch_size * cfg.max_seq_length * world / dt  # train_multi_gpu.py:751-755
+            print(json.dumps({"step": step, "loss": lv, "ms": dt * 1e3, "tokens_per_s": toks}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,285 @@
+"""GPU parity of the module/autograd surface (Linear, LayerNormLinear, LayerNormMLP, MultiheadAttention,
+fp8_autocast state machine, te_llama counterpart) against the CPU oracle and the HF bf16 layer."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fp8_oracle as O
+from tests.util import assert_gemm_close, bf16_bits, bits_to_bf16
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def te(dev):
+    import llm_fp8_amd.pytorch as te_
+    from llm_fp8_amd.pytorch.fp8 import FP8GlobalStateManager
+    FP8GlobalStateManager.reset()
+    yield te_
+    FP8GlobalStateManager.reset()
+
+
+def _recipes():
+    from llm_fp8_amd.common.recipe import DelayedScaling, Format, MXFP8BlockScaling
+    return DelayedScaling, Format, MXFP8BlockScaling
+
+
+def _f(t):
+    return t.detach().float().cpu().numpy()
+
+
+@pytest.mark.parametrize("fmt_name,fwd,bwd", [("HYBRID", O.E4M3, O.E5M2), ("E4M3", O.E4M3, O.E4M3)])
+@pytest.mark.parametrize("use_bias", [False, True])
+def test_linear_delayed_scaling_three_steps_vs_oracle(te, dev, fmt_name, fwd, bwd, use_bias):
+    DelayedScaling, Format, _ = _recipes()
+    recipe = DelayedScaling(fp8_format=getattr(Format, fmt_name), amax_history_len=4, amax_compute_algo="max")
+    M, K, N = 64, 128, 96
+    g = torch.Generator().manual_seed(7)
+    lin = te.Linear(K, N, bias=use_bias, params_dtype=torch.bfloat16, device=dev)
+    with torch.no_grad():
+        lin.weight.copy_((torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16))
+        if use_bias:
+            lin.bias.copy_((torch.randn(N, generator=g)).to(torch.bfloat16))
+    orc = O.DelayedLinearOracle(fwd, bwd, history_len=4, algo="max")
+    wbits = bf16_bits(lin.weight)
+    bbits = bf16_bits(lin.bias) if use_bias else None
+    for step in range(3):
+        x = (torch.randn(M, K, generator=g) * (step + 1)).to(torch.bfloat16)
+        dy = (torch.randn(M, N, generator=g) / 32).to(torch.bfloat16)
+        xd = x.to(dev).requires_grad_(True)
+        with te.fp8_autocast(enabled=True, fp8_recipe=recipe):
+            y = lin(xd)
+        y.backward(dy.to(dev))
+        y_ref = O.bf16_bits_to_f32(orc.forward(bf16_bits(x), wbits, bbits))
+        orc.end_forward()
+        dx_ref, dw_ref, db_ref = orc.backward(bf16_bits(dy))
+        orc.end_backward()
+        # the oracle's bf16 outputs carry 1 bf16 ulp of their own; compare in f32 with the GEMM tolerance
+        assert_gemm_close(_f(y), y_ref, f"y step {step}")
+        assert_gemm_close(_f(xd.grad), O.bf16_bits_to_f32(dx_ref), f"dx step {step}")
+        assert_gemm_close(_f(lin.weight.grad), O.bf16_bits_to_f32(dw_ref), f"dw step {step}")
+        if use_bias:
+            np.testing.assert_allclose(_f(lin.bias.grad), O.bf16_bits_to_f32(db_ref), rtol=2 ** -7, atol=1e-3)
+        lin.weight.grad = None
+        if use_bias:
+            lin.bias.grad = None
+        # delayed-scaling state: bit-exact (amaxes of the given inputs, K3 arithmetic)
+        sf, sb = lin._meta_fwd.state(), lin._meta_bwd.state()
+        np.testing.assert_array_equal(sf["scale"].cpu().numpy()[:2], orc.s_fwd[:2], err_msg=f"fwd scale step {step}")
+        np.testing.assert_array_equal(sf["amax_history"].cpu().numpy()[:, :2], orc.h_fwd[:, :2])
+        np.testing.assert_array_equal(sb["scale"].cpu().numpy()[:1], orc.s_bwd[:1], err_msg=f"bwd scale step {step}")
+        np.testing.assert_array_equal(sb["amax_history"].cpu().numpy()[:, :1], orc.h_bwd[:, :1])
+        np.testing.assert_array_equal(sf["scale_inv"].cpu().numpy()[:2], orc.si_fwd[:2])
+
+
+def test_linear_mxfp8_vs_oracle(te, dev):
+    _, Format, MXFP8BlockScaling = _recipes()
+    recipe = MXFP8BlockScaling(fp8_format=Format.E4M3)
+    M, K, N = 64, 128, 96
+    g = torch.Generator().manual_seed(8)
+    lin = te.Linear(K, N, bias=True, params_dtype=torch.bfloat16, device=dev)
+    with torch.no_grad():
+        lin.weight.copy_((torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16))
+        lin.bias.copy_(torch.randn(N, generator=g).to(torch.bfloat16))
+    x = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))).to(torch.bfloat16)
+    dy = (torch.randn(M, N, generator=g) / 32).to(torch.bfloat16)
+    xd = x.to(dev).requires_grad_(True)
+    with te.fp8_autocast(enabled=True, fp8_recipe=recipe):
+        y = lin(xd)
+    y.backward(dy.to(dev))
+    y_r, dx_r, dw_r, db_r = O.mxfp8_linear_fwd_bwd(bf16_bits(x), bf16_bits(lin.weight), bf16_bits(dy), bf16_bits(lin.bias))
+    assert_gemm_close(_f(y), O.bf16_bits_to_f32(y_r), "mx y")
+    assert_gemm_close(_f(xd.grad), O.bf16_bits_to_f32(dx_r), "mx dx")
+    assert_gemm_close(_f(lin.weight.grad), O.bf16_bits_to_f32(dw_r), "mx dw")
+    np.testing.assert_allclose(_f(lin.bias.grad), O.bf16_bits_to_f32(db_r), rtol=2 ** -7, atol=1e-3)
+
+
+def test_layernorm_linear_split_weights_share_one_slot(te, dev):
+    """q|k|v as three Parameters == one Linear on the concatenated weight (same single amax/scale slot)."""
+    DelayedScaling, Format, _ = _recipes()
+    recipe = DelayedScaling(fp8_format=Format.HYBRID, amax_history_len=4, amax_compute_algo="max")
+    h, sizes = 128, {"query_": 64, "key_": 32, "value_": 32}
+    torch.manual_seed(3)
+    lnl = te.LayerNormLinear(h, 128, eps=1e-5, bias=False, normalization="RMSNorm", parameters_split=sizes,
+                             params_dtype=torch.bfloat16, device=dev)
+    with torch.no_grad():
+        lnl.key_weight.mul_(5.0)
+        lnl.layer_norm_weight.copy_(torch.rand(h) + 0.5)
+    ref = te.Linear(h, 128, bias=False, params_dtype=torch.bfloat16, device=dev)
+    with torch.no_grad():
+        ref.weight.copy_(torch.cat([lnl.query_weight, lnl.key_weight, lnl.value_weight], 0))
+    x = torch.randn(4, 16, h, device=dev, dtype=torch.bfloat16)
+    for _ in range(2):
+        xa = x.clone().requires_grad_(True)
+        xb = x.clone().requires_grad_(True)
+        with te.fp8_autocast(enabled=True, fp8_recipe=recipe):
+            ya = lnl(xa)
+        with te.fp8_autocast(enabled=True, fp8_recipe=recipe):
+            yb = ref(torch.nn.functional.rms_norm(xb, (h,), lnl.layer_norm_weight, 1e-5))
+        assert torch.equal(ya, yb)
+        gy = torch.randn_like(ya) / 16
+        ya.backward(gy)
+        yb.backward(gy)
+        assert torch.equal(xa.grad, xb.grad)
+        gcat = torch.cat([lnl.query_weight.grad, lnl.key_weight.grad, lnl.value_weight.grad], 0)
+        assert torch.equal(gcat, ref.weight.grad)
+        for p in list(lnl.parameters()) + list(ref.parameters()):
+            p.grad = None
+    assert torch.equal(lnl._meta_fwd.state()["scale"], ref._meta_fwd.state()["scale"])
+
+
+def test_layernorm_mlp_matches_two_linears_and_bf16(te, dev):
+    DelayedScaling, Format, _ = _recipes()
+    recipe = DelayedScaling(fp8_format=Format.E4M3, amax_history_len=16, amax_compute_algo="max")
+    h, f = 128, 256
+    torch.manual_seed(5)
+    mlp = te.LayerNormMLP(h, f, eps=1e-5, normalization="RMSNorm", activation="swiglu", params_dtype=torch.bfloat16, device=dev)
+    with torch.no_grad():
+        mlp.fc1_bias.normal_(0, 0.1)
+        mlp.fc2_bias.normal_(0, 0.1)
+    assert mlp.fc1_weight.shape == (2 * f, h) and mlp.fc2_weight.shape == (h, f)
+    x = torch.randn(2, 32, h, device=dev, dtype=torch.bfloat16)
+    # warm the scales (first iteration quantises with scale 1)
+    for _ in range(2):
+        with te.fp8_autocast(enabled=True, fp8_recipe=recipe):
+            y8 = mlp(x.clone().requires_grad_(True))
+        y8.sum().backward()
+    xr = x.clone().requires_grad_(True)
+    with te.fp8_autocast(enabled=True, fp8_recipe=recipe):
+        y8 = mlp(xr)
+    yb = mlp(x)  # outside autocast: plain bf16 path of the same module
+    rel = (y8.float() - yb.float()).norm() / yb.float().norm()
+    assert rel < 0.08, f"fp8 vs bf16 relative error {rel:.4f}"
+    y8.backward(torch.randn_like(y8) / 16)
+    for p in (mlp.fc1_weight, mlp.fc2_weight, mlp.fc1_bias, mlp.fc2_bias, mlp.layer_norm_weight):
+        assert p.grad is not None and torch.isfinite(p.grad.float()).all()
+    assert mlp._meta_fwd.n == 6 and mlp._meta_bwd.n == 4  # G = 2 (SURVEY Appendix A "Slots")
+
+
+def test_autocast_state_machine(te, dev):
+    """Outermost exit updates all forward slots once; nested exits do not; no update under no_grad; backward
+    update fires after the first module's backward; disabled autocast runs bf16."""
+    DelayedScaling, Format, _ = _recipes()
+    from llm_fp8_amd.pytorch.fp8 import FP8GlobalStateManager as S
+    r_in = DelayedScaling(fp8_format=Format.HYBRID, amax_history_len=4, amax_compute_algo="max")
+    r_out = DelayedScaling(fp8_format=Format.HYBRID, amax_history_len=8, amax_compute_algo="most_recent")
+    a = te.Linear(64, 64, bias=False, params_dtype=torch.bfloat16, device=dev)
+    b = te.Linear(64, 64, bias=False, params_dtype=torch.bfloat16, device=dev)
+    x = torch.randn(16, 64, device=dev, dtype=torch.bfloat16, requires_grad=True)
+    with te.fp8_autocast(enabled=True, fp8_recipe=r_out):
+        with te.fp8_autocast(enabled=True, fp8_recipe=r_in):
+            h = a(x)
+            assert S.FP8_AUTOCAST_DEPTH == 2
+        # inner exit: nothing updated yet, amax still in row 0
+        assert a._meta_fwd.state()["amax_history"][0, 0].item() > 0
+        assert a._meta_fwd.state()["scale"][0].item() == 1.0
+        y = b(h)
+    assert S.FP8_AUTOCAST_DEPTH == 0
+    sa, sb = a._meta_fwd.state(), b._meta_fwd.state()
+    assert sa["amax_history"].shape[0] == 4 and sb["amax_history"].shape[0] == 8  # each module under its own recipe
+    assert sa["scale"][0].item() > 1.0 and sb["scale"][0].item() > 1.0 and sa["amax_history"][0].abs().sum().item() == 0
+    # backward: module `a` was the first FP8 module -> bwd update happens in its backward (the last one)
+    assert b._meta_bwd.state()["scale"][0].item() == 1.0
+    y.sum().backward()
+    assert b._meta_bwd.state()["scale"][0].item() > 1.0 and a._meta_bwd.state()["scale"][0].item() > 1.0
+    # no_grad (the reference's eval loop, train_fp8.py:323-327): quantise with current scales, never update
+    before = a._meta_fwd.state()
+    with torch.no_grad():
+        with te.fp8_autocast(enabled=True, fp8_recipe=r_in):
+            a(x)
+    after = a._meta_fwd.state()
+    assert torch.equal(before["scale"], after["scale"]) and after["amax_history"][0, 0].item() > 0
+    # enabled=False -> bf16 path, bit-identical to F.linear
+    with te.fp8_autocast(enabled=False):
+        yb = a(x)
+    assert torch.equal(yb, torch.nn.functional.linear(x, a.weight))
+
+
+def test_extra_state_roundtrip(te, dev):
+    DelayedScaling, Format, _ = _recipes()
+    r = DelayedScaling(fp8_format=Format.HYBRID, amax_history_len=4, amax_compute_algo="max")
+    a = te.Linear(64, 32, params_dtype=torch.bfloat16, device=dev)
+    x = torch.randn(16, 64, device=dev, dtype=torch.bfloat16, requires_grad=True)
+    with te.fp8_autocast(enabled=True, fp8_recipe=r):
+        a(x).sum().backward()
+    sd = a.state_dict()
+    assert "_extra_state" in sd
+    b = te.Linear(64, 32, params_dtype=torch.bfloat16, device=dev)
+    b.load_state_dict(sd)
+    with te.fp8_autocast(enabled=True, fp8_recipe=r):
+        yb = b(x)
+    with te.fp8_autocast(enabled=True, fp8_recipe=r):
+        ya = a(x)
+    assert torch.equal(ya, yb)
+
+
+def _tiny_cfg():
+    from llm_fp8_amd import llama
+    return llama.llama_config("llama-3.2-1b", num_hidden_layers=2, hidden_size=256, intermediate_size=512,
+                              num_attention_heads=4, num_key_value_heads=2, head_dim=64, vocab_size=1024,
+                              max_position_embeddings=256, rope_theta=10000.0)
+
+
+@pytest.mark.parametrize("scenario", ["default", "hybrid", "mxfp8"])
+def test_te_decoder_layer_vs_hf_bf16_layer(te, dev, scenario):
+    """The TE-shaped layer with replace_params-mapped weights tracks HF's bf16 LlamaDecoderLayer
+    (rope_theta set to TE's base 10000 so both use the same RoPE)."""
+    from transformers.models.llama.modeling_llama import LlamaForCausalLM
+    from llm_fp8_amd import llama
+    cfg = _tiny_cfg()
+    torch.manual_seed(0)
+    hf = LlamaForCausalLM(cfg).to(dev).to(torch.bfloat16)
+    tem = llama.TELlamaForCausalLM.from_hf_state_dict(hf.state_dict(), cfg, scenario).to(dev)
+    names = dict(tem.named_parameters())
+    assert "model.layers.0.self_attention.layernorm_qkv.query_weight" in names
+    assert "model.layers.1.layernorm_mlp.fc1_weight" in names and "model.layers.1.layernorm_mlp.fc2_bias" in names
+    f = cfg.intermediate_size
+    assert torch.equal(names["model.layers.0.layernorm_mlp.fc1_weight"][:f], hf.model.layers[0].mlp.gate_proj.weight)
+    assert torch.equal(names["model.layers.0.layernorm_mlp.fc1_weight"][f:], hf.model.layers[0].mlp.up_proj.weight)
+    ids = torch.randint(0, cfg.vocab_size, (2, 64), device=dev)
+    hf.train(); tem.train()
+    for _ in range(3):  # let delayed scaling settle
+        out = tem(input_ids=ids, labels=ids)
+        out.loss.backward()
+        tem.zero_grad()
+    ref = hf(input_ids=ids, labels=ids)
+    out = tem(input_ids=ids, labels=ids)
+    rel = (out.logits.float() - ref.logits.float()).norm() / ref.logits.float().norm()
+    assert rel < 0.08, f"{scenario}: logits relative error {rel:.4f}"
+    assert abs(out.loss.item() - ref.loss.item()) < 0.05 * abs(ref.loss.item())
+    out.loss.backward(); ref.loss.backward()
+    g8 = tem.model.layers[0].self_attention.proj.weight.grad.float()
+    gb = hf.model.layers[0].self_attn.o_proj.weight.grad.float()
+    grel = (g8 - gb).norm() / gb.norm()
+    assert grel < 0.25, f"{scenario}: o_proj grad relative error {grel:.4f}"
+
+
+@pytest.mark.parametrize("use_te,scenario", [(True, "default"), (True, "mxfp8"), (False, "default")])
+def test_train_steps_run_and_update_once_per_step(te, dev, use_te, scenario):
+    from llm_fp8_amd import llama, train
+    from llm_fp8_amd.pytorch.fp8 import FP8GlobalStateManager as S
+    cfg = train.TrainingConfig(model_name="llama-3.2-1b", batch_size=2, max_seq_length=64, mixed_precision="fp8",
+                               fp8_scenario=scenario, use_te=use_te, num_hidden_layers=2, vocab_size=2048,
+                               learning_rate=1e-3, num_warmup_steps=0)
+    torch.manual_seed(0)
+    model = train.prepare_model(train.create_model(cfg, dev), cfg)
+    lm_head = model.lm_head
+    assert isinstance(lm_head, te.Linear) and lm_head.weight is model.model.embed_tokens.weight  # tie kept
+    if not use_te:
+        assert isinstance(model.model.layers[0].self_attn.q_proj, te.Linear)
+    opt, sched = train.create_optimizer(model, cfg)
+    model.train()
+    batch = train.synthetic_batch(cfg, 2048, dev)
+    losses = []
+    for step in range(6):
+        losses.append(train.train_step(model, batch, opt, sched, cfg).item())
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    # exactly one forward update per step: the lm_head history (outer recipe) has rolled 6 times
+    hist = lm_head._meta_fwd.state()["amax_history"]
+    assert hist[0].abs().sum().item() == 0
+    n_nonzero = int((hist[:, 0] > 0).sum().item())
+    assert n_nonzero == min(6, hist.shape[0] - 1), n_nonzero
+    model.eval()
+    with torch.no_grad():
+        out = model(**batch)
+    assert torch.isfinite(out.loss)
