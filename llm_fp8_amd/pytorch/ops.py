@@ -7,6 +7,7 @@ from typing import Optional, Tuple
 import torch
 
 from .. import _lib
+from .profiler import KernelTimer
 
 E4M3, E5M2 = _lib.MI_FMT_E4M3, _lib.MI_FMT_E5M2
 FP8_MAX = {E4M3: 448.0, E5M2: 57344.0}
@@ -45,10 +46,15 @@ def cast_amax(x: torch.Tensor, scale: torch.Tensor, amax: Optional[torch.Tensor]
         assert y.dtype == torch.uint8 and y.shape == (R, C) and y.stride(1) == 1
     if yT is not None:
         assert yT.dtype == torch.uint8 and yT.shape == (C, R) and yT.stride(1) == 1
-    lib = _lib.load()
-    rc = lib.mi_cast_amax(x.data_ptr(), _ptr(y), _ptr(yT), scale.data_ptr(), _ptr(amax), R, C,
-                          y.stride(0) if y is not None else C, yT.stride(0) if yT is not None else R,
-                          fmt, _stream())
+    args = (x.data_ptr(), _ptr(y), _ptr(yT), scale.data_ptr(), _ptr(amax), R, C,
+            y.stride(0) if y is not None else C, yT.stride(0) if yT is not None else R, fmt, _stream())
+    t = KernelTimer.active
+    if t is None:
+        rc = _lib.load().mi_cast_amax(*args)
+    else:
+        nb = R * C * (2 + (y is not None) + (yT is not None))
+        with t.span("cast_amax", f"{R}x{C}", float(R * C), float(nb)):
+            rc = _lib.load().mi_cast_amax(*args)
     _lib.check(rc, "mi_cast_amax")
     return y, yT
 
@@ -83,10 +89,15 @@ def gemm_fp8(a8: torch.Tensor, b8: torch.Tensor, sa_inv: torch.Tensor, sb_inv: t
     assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype in (torch.bfloat16, torch.float32)
     if bias is not None:
         assert bias.dtype == torch.bfloat16 and bias.numel() == N and bias.is_contiguous()
-    rc = _lib.load().mi_gemm_fp8(a8.data_ptr(), b8.data_ptr(), out.data_ptr(), sa_inv.data_ptr(),
-                                 sb_inv.data_ptr(), _ptr(bias), M, N, K, a8.stride(0), b8.stride(0),
-                                 out.stride(0), fmt_a, fmt_b, 0 if out.dtype == torch.bfloat16 else 1,
-                                 algo, _stream())
+    args = (a8.data_ptr(), b8.data_ptr(), out.data_ptr(), sa_inv.data_ptr(), sb_inv.data_ptr(), _ptr(bias), M, N, K,
+            a8.stride(0), b8.stride(0), out.stride(0), fmt_a, fmt_b, 0 if out.dtype == torch.bfloat16 else 1, algo,
+            _stream())
+    t = KernelTimer.active
+    if t is None:
+        rc = _lib.load().mi_gemm_fp8(*args)
+    else:
+        with t.span("gemm_fp8", f"{M}x{N}x{K}", 2.0 * M * N * K, M * K + N * K + out.element_size() * M * N):
+            rc = _lib.load().mi_gemm_fp8(*args)
     _lib.check(rc, "mi_gemm_fp8")
     return out
 
@@ -103,8 +114,14 @@ def mxfp8_quantize(x: torch.Tensor, fmt: int = E4M3, rowwise: bool = True, colwi
     if colwise:
         y_colT = torch.empty((C, R), dtype=torch.uint8, device=x.device)
         s_colT = torch.empty((C, R // 32), dtype=torch.uint8, device=x.device)
-    rc = _lib.load().mi_mxfp8_quantize(x.data_ptr(), _ptr(y_row), _ptr(s_row), _ptr(y_colT), _ptr(s_colT),
-                                       R, C, fmt, _stream())
+    args = (x.data_ptr(), _ptr(y_row), _ptr(s_row), _ptr(y_colT), _ptr(s_colT), R, C, fmt, _stream())
+    t = KernelTimer.active
+    if t is None:
+        rc = _lib.load().mi_mxfp8_quantize(*args)
+    else:
+        nb = R * C * (2 + (1 + 1 / 32) * (int(rowwise) + int(colwise)))
+        with t.span("mxfp8_quantize", f"{R}x{C}", float(R * C), float(nb)):
+            rc = _lib.load().mi_mxfp8_quantize(*args)
     _lib.check(rc, "mi_mxfp8_quantize")
     return y_row, s_row, y_colT, s_colT
 
@@ -120,8 +137,13 @@ def gemm_mxfp8(a8, sa, b8, sb, fmt_a: int = E4M3, fmt_b: int = E4M3, bias=None, 
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=a8.device)
     assert out.is_contiguous() and out.shape == (M, N)
-    rc = _lib.load().mi_gemm_mxfp8(a8.data_ptr(), sa.data_ptr(), b8.data_ptr(), sb.data_ptr(), out.data_ptr(),
-                                   _ptr(bias), M, N, K, fmt_a, fmt_b,
-                                   0 if out.dtype == torch.bfloat16 else 1, algo, _stream())
+    args = (a8.data_ptr(), sa.data_ptr(), b8.data_ptr(), sb.data_ptr(), out.data_ptr(), _ptr(bias), M, N, K, fmt_a,
+            fmt_b, 0 if out.dtype == torch.bfloat16 else 1, algo, _stream())
+    t = KernelTimer.active
+    if t is None:
+        rc = _lib.load().mi_gemm_mxfp8(*args)
+    else:
+        with t.span("gemm_mxfp8", f"{M}x{N}x{K}", 2.0 * M * N * K, M * K + N * K + out.element_size() * M * N):
+            rc = _lib.load().mi_gemm_mxfp8(*args)
     _lib.check(rc, "mi_gemm_mxfp8")
     return out
