@@ -249,6 +249,171 @@ __global__ __launch_bounds__(512, 2) void gemm_256_2ph(const uint8_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_256_8ph: 256x256x128 tile, 8 waves, two wave groups (waves 0-3 / 4-7 = the two waves of each
+// SIMD) running half a phase apart ("ping-pong"): while one group issues its 8 MFMAs of a phase the
+// other reads fragments from LDS and issues LDS-DMA prefetches.  Four phases per K-tile:
+//     p0: read A0 (4 frags) + B0 (2)   mfma C[0][*][0][*]      stage (t+1, B1)
+//     p1: read B1 (2)                  mfma C[0][*][1][*]      stage (t+1, A1)
+//     p2: read A1 (4)                  mfma C[1][*][1][*]      stage (t+2, A0)
+//     p3: --                           mfma C[1][*][0][*]      stage (t+2, B0)
+// LDS: 2 K-tile buffers x {A0, A1, B0, B1} half-tiles (128 rows x 128 B = 16 pieces, 2 per wave).
+// A wave's 128x64 output is 2x2 blocks of 64x32: rows 128*mh + 64*wr + [0,64), cols 128*nh + 32*wc + [0,32),
+// so every half-tile is read in exactly ONE phase by all waves and can be restaged two phases later:
+// each LDS-DMA has >= 5 phases (~2.5k cycles) to land.  Hazards (barrier slots, group 1 one slot late):
+//   RAW  a half-tile first read in phase p+1 is retired by `s_waitcnt vmcnt(8)` (4 younger half-tile
+//        stages may stay in flight) before the barrier that closes the load segment of phase p;
+//   WAR  a half-tile read in phase p (both groups: slots 2p, 2p+1, retired by lgkmcnt(0) at the start
+//        of the following slot) is restaged no earlier than phase p+2 (slot 2p+4).
+// vmcnt is never drained inside the loop; barriers are raw s_barrier (a __syncthreads would drain it).
+// Past the last K-tile the stages re-fetch tile nk-1 into a dead buffer so the counts stay uniform.
+constexpr int kHalfBytes = 128 * BK;  // 16 KiB
+constexpr int kOffA0 = 0, kOffA1 = kHalfBytes, kOffB0 = 2 * kHalfBytes, kOffB1 = 3 * kHalfBytes;
+
+__device__ __forceinline__ void stage_half(const uint8_t* __restrict__ g_row0, int64_t ld, int k_byte, uint8_t* lds_half,
+                                           int wave, int lane) {
+  const int lr = lane >> 3, lc = lane & 7;
+  const int src_chunk = lc ^ swz_f(lr);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int piece = wave * 2 + i;
+    const uint8_t* src = g_row0 + (int64_t)(piece * 8 + lr) * ld + k_byte + src_chunk * 16;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_half + piece * 1024), 16, 0, 0);
+  }
+}
+
+#define MI_PHASE_SYNC_BEFORE_MFMA()                  \
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   \
+  __builtin_amdgcn_s_barrier();                      \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+  __builtin_amdgcn_sched_barrier(0);                 \
+  __builtin_amdgcn_s_setprio(1);
+#define MI_PHASE_END()            \
+  __builtin_amdgcn_s_setprio(0);  \
+  __builtin_amdgcn_s_barrier();   \
+  __builtin_amdgcn_sched_barrier(0);
+
+template <int FA, int FB, int OUT>
+__global__ __launch_bounds__(512, 2) void gemm_256_8ph(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
+                                                       void* __restrict__ D, const float* __restrict__ sa_inv,
+                                                       const float* __restrict__ sb_inv,
+                                                       const uint16_t* __restrict__ bias, int M, int N, int K,
+                                                       int64_t lda, int64_t ldb, int64_t ldd, int tiles_m,
+                                                       int tiles_n) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  int tm, tn;
+  tile_of_block(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
+  const uint8_t* gA0 = A + (int64_t)tm * BM * lda;  // A half h starts 128*h rows further
+  const uint8_t* gB0 = B + (int64_t)tn * BN * ldb;
+  const uint8_t* gA1 = gA0 + 128 * lda;
+  const uint8_t* gB1 = gB0 + 128 * ldb;
+  v4f acc[2][4][2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[a][i][b][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+  const int nk = K / BK;
+  const int last = nk - 1;
+  uint8_t* buf0 = lds;
+  uint8_t* buf1 = lds + kBufBytes;
+  // prologue: K-tile 0 complete + (1, A0), (1, B0) in flight
+  stage_half(gA0, lda, 0, buf0 + kOffA0, wave, lane);
+  stage_half(gB0, ldb, 0, buf0 + kOffB0, wave, lane);
+  stage_half(gB1, ldb, 0, buf0 + kOffB1, wave, lane);
+  stage_half(gA1, lda, 0, buf0 + kOffA1, wave, lane);
+  {
+    const int k1 = min(1, last) * BK;
+    stage_half(gA0, lda, k1, buf1 + kOffA0, wave, lane);
+    stage_half(gB0, ldb, k1, buf1 + kOffB0, wave, lane);
+  }
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier slot behind group 0
+
+  v8i af[4], b0f[2], b1f[2];
+  auto ktile = [&](uint8_t* cur, uint8_t* oth, int t) {
+    const int kb1 = min(t + 1, last) * BK, kb2 = min(t + 2, last) * BK;
+    // ---- phase 0
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b0f[j] = read_frag(cur + kOffB0, wc * 2 + j, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = read_frag(cur + kOffA0, wr * 4 + i, lane);
+    stage_half(gB1, ldb, kb1, oth + kOffB1, wave, lane);
+    MI_PHASE_SYNC_BEFORE_MFMA();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[0][i][0][j] = mfma_ba<FA, FB>(af[i], b0f[j], acc[0][i][0][j], kUnitScale, kUnitScale);
+    MI_PHASE_END();
+    // ---- phase 1
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b1f[j] = read_frag(cur + kOffB1, wc * 2 + j, lane);
+    stage_half(gA1, lda, kb1, oth + kOffA1, wave, lane);
+    MI_PHASE_SYNC_BEFORE_MFMA();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[0][i][1][j] = mfma_ba<FA, FB>(af[i], b1f[j], acc[0][i][1][j], kUnitScale, kUnitScale);
+    MI_PHASE_END();
+    // ---- phase 2
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = read_frag(cur + kOffA1, wr * 4 + i, lane);
+    stage_half(gA0, lda, kb2, cur + kOffA0, wave, lane);
+    MI_PHASE_SYNC_BEFORE_MFMA();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[1][i][1][j] = mfma_ba<FA, FB>(af[i], b1f[j], acc[1][i][1][j], kUnitScale, kUnitScale);
+    MI_PHASE_END();
+    // ---- phase 3
+    stage_half(gB0, ldb, kb2, cur + kOffB0, wave, lane);
+    MI_PHASE_SYNC_BEFORE_MFMA();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[1][i][0][j] = mfma_ba<FA, FB>(af[i], b0f[j], acc[1][i][0][j], kUnitScale, kUnitScale);
+    MI_PHASE_END();
+  };
+  for (int t = 0; t < nk; t += 2) {
+    ktile(buf0, buf1, t);
+    if (t + 1 < nk) ktile(buf1, buf0, t + 1);
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the dead tail prefetches before the LDS is released
+
+  const float alpha = (*sa_inv) * (*sb_inv);
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t n = (int64_t)tn * BN + 128 * b + wc * 32 + j * 16 + fq * 4;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = bf16_bits_to_float(bias[n + e]);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t m = (int64_t)tm * BM + 128 * a + wr * 64 + i * 16 + fr;
+          v4f v = acc[a][i][b][j] * alpha;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bv[e];
+          store4<OUT>(D, ldd, m, n, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 template <int FA, int FB, int OUT>
 static int launch_fmt(const void* A, const void* B, void* D, const float* sa_inv, const float* sb_inv,
                       const void* SA, const void* SB, const void* bias, int64_t M, int64_t N, int64_t K,
@@ -258,6 +423,10 @@ static int launch_fmt(const void* A, const void* B, void* D, const float* sa_inv
   if (algo == 2 && !mx) {
     int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
     hipLaunchKernelGGL((gemm_256_2ph<FA, FB, OUT>), dim3(tiles_m * tiles_n), dim3(512), 0, st, a, b, D, sa_inv, sb_inv,
+                       bp, (int)M, (int)N, (int)K, lda, ldb, ldd, tiles_m, tiles_n);
+  } else if (algo == 3 && !mx) {
+    int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
+    hipLaunchKernelGGL((gemm_256_8ph<FA, FB, OUT>), dim3(tiles_m * tiles_n), dim3(512), 0, st, a, b, D, sa_inv, sb_inv,
                        bp, (int)M, (int)N, (int)K, lda, ldb, ldd, tiles_m, tiles_n);
   } else {
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
@@ -309,7 +478,7 @@ static int pick_algo(int algo, int64_t M, int64_t N, int64_t K, const char* who)
       set_error("%s: algo %d needs M,N %% 256 == 0 and K %% 128 == 0", who, algo);
       return MI_ERR_SHAPE;
     }
-    return 2;
+    return algo;
   }
   set_error("%s: unknown algo %d", who, algo);
   return MI_ERR_ARG;

@@ -157,17 +157,19 @@ def assert_mfma_close(got, ref, a8, b8, fa, fb, alpha):
     assert np.sqrt(np.mean(diff ** 2)) <= 2.0 ** -12 * np.sqrt(np.mean(mag ** 2))
 
 
-GEMM_SHAPES = [(64, 96, 128), (16, 16, 16), (8, 24, 48), (200, 136, 400), (256, 256, 128), (256, 512, 384),
+GEMM_SHAPES = [(256, 256, 256), (512, 768, 640), (64, 96, 128), (16, 16, 16), (8, 24, 48), (200, 136, 400), (256, 256, 128), (256, 512, 384),
                (512, 256, 3072), (256, 5120, 3072), (768, 1024, 256)]
 
 
 @pytest.mark.parametrize("shape", GEMM_SHAPES)
 @pytest.mark.parametrize("fa,fb", [(O.E4M3, O.E4M3), (O.E5M2, O.E4M3), (O.E4M3, O.E5M2), (O.E5M2, O.E5M2)])
-@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("algo", [0, 1, 2, 3])
 def test_gemm_fp8_vs_oracle(ops, dev, shape, fa, fb, algo):
     M, N, K = shape
     if algo == 1 and M * N * K > 256 * 512 * 3072:
         pytest.skip("generic path covered at smaller sizes")
+    if algo in (2, 3) and (M % 256 or N % 256 or K % 128):
+        pytest.skip("fast kernels need 256/256/128-aligned shapes")
     a8 = _rand_fp8((M, K), fa, 1 + M, 4.0 if fa == O.E4M3 else 64.0)
     b8 = _rand_fp8((N, K), fb, 2 + N, 4.0 if fb == O.E4M3 else 64.0)
     sa, sb = np.float32(1 / 7.3), np.float32(1 / 0.011)
@@ -185,7 +187,7 @@ def test_gemm_fp8_vs_oracle(ops, dev, shape, fa, fb, algo):
     assert_mfma_close(d32.cpu().numpy(), ref, a8, b8, fa, fb, float(sa) * float(sb))
 
 
-@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("algo", [1, 2, 3])
 def test_gemm_identity_with_asymmetric_b(ops, dev, algo):
     """A = I (padded), B asymmetric small integers: exact result, catches row/col swaps and K-permutation
     mismatches between the A and B fragments."""
