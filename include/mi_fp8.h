@@ -80,8 +80,10 @@ int mi_scale_update(float* amax_history, float* scale, float* scale_inv, const f
  *   D[m*ldd + n] = bf16( (sum_k A[m*lda+k] * B[n*ldb+k]) * (*sa_inv * *sb_inv) + bias[n] )
  * A: fp8 [M,K] fmt_a, B: fp8 [N,K] fmt_b, D: bf16 [M,N] (out_dtype 0) or fp32 (out_dtype 1).
  * bias: bf16 [N] or NULL.  M, N multiples of 16 (8 for the generic path), K multiple of 16.
- * algo: 0 = auto, 1 = generic 64x64 tile, 2 = 256x256 two-phase, 3 = 256x256 eight-phase ping-pong
- * (2/3 need M,N % 256 == 0 and K % 128 == 0; auto falls back to 1 otherwise).
+ * algo: 0 = auto, 1 = generic 64x64 tile, 2 = 256x256 two-phase, 3 = 256x256 eight-phase ping-pong,
+ *       4 = persistent eight-phase (one workgroup per CU, epilogue overlapped with the next tile).
+ * 2/3 need M,N % 256 == 0 and K % 128 == 0; 4 additionally K % 256 == 0, bf16 output, no bias and
+ * operands below 2 GiB.  auto picks 4, else 3, else 1.  (13-15 are timing-only diagnostic builds.)
  */
 int mi_gemm_fp8(const void* A, const void* B, void* D, const float* sa_inv, const float* sb_inv,
                 const void* bias_bf16, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,

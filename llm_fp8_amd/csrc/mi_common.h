@@ -27,6 +27,7 @@ int hip_fail(hipError_t e, const char* what);
   } while (0)
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned int u32;
@@ -38,8 +39,12 @@ __device__ __forceinline__ u32 float_to_bf16_bits(float f) {
   __bf16 h = (__bf16)f;
   return (u32)__builtin_bit_cast(unsigned short, h);
 }
+// two fp32 -> packed bf16x2 (RNE, NaN kept): one v_cvt_pk_bf16_f32
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u32 pack_bf16x2(float lo, float hi) {
-  return float_to_bf16_bits(lo) | (float_to_bf16_bits(hi) << 16);
+  f32x2 v = {lo, hi};
+  return __builtin_bit_cast(u32, __builtin_convertvector(v, bf16x2));
 }
 
 template <int FMT>

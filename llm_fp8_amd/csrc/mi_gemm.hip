@@ -30,6 +30,7 @@
 // Replaces the cuBLASLt FP8 GEMMs behind te.Linear / LayerNormLinear / LayerNormMLP on the
 // reference path (te_llama.py:45-63,76-80; Appendix B shapes).
 #include "mi_common.h"
+#include <type_traits>
 
 namespace mi {
 
@@ -292,7 +293,7 @@ __device__ __forceinline__ void stage_half(const uint8_t* __restrict__ g_row0, i
   __builtin_amdgcn_s_barrier();   \
   __builtin_amdgcn_sched_barrier(0);
 
-template <int FA, int FB, int OUT>
+template <int FA, int FB, int OUT, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_256_8ph(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
                                                        void* __restrict__ D, const float* __restrict__ sa_inv,
                                                        const float* __restrict__ sb_inv,
@@ -381,9 +382,25 @@ __global__ __launch_bounds__(512, 2) void gemm_256_8ph(const uint8_t* __restrict
       for (int j = 0; j < 2; ++j) acc[1][i][0][j] = mfma_ba<FA, FB>(af[i], b0f[j], acc[1][i][0][j], kUnitScale, kUnitScale);
     MI_PHASE_END();
   };
+  unsigned long long c0 = 0, r0 = 0;
+  if (ABL == 2) {
+    c0 = __builtin_amdgcn_s_memtime();
+    r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+  }
   for (int t = 0; t < nk; t += 2) {
     ktile(buf0, buf1, t);
     if (t + 1 < nk) ktile(buf1, buf0, t + 1);
+  }
+  if (ABL == 2) {
+    unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {
+      unsigned long long* dbg = (unsigned long long*)bias + (size_t)blockIdx.x * 2;
+      dbg[0] = c1 - c0;
+      dbg[1] = r1 - r0;
+    }
+    bias = nullptr;
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // retire the dead tail prefetches before the LDS is released
@@ -408,12 +425,254 @@ __global__ __launch_bounds__(512, 2) void gemm_256_8ph(const uint8_t* __restrict
           v4f v = acc[a][i][b][j] * alpha;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += bv[e];
-          store4<OUT>(D, ldd, m, n, v);
+          if (ABL >= 1) {  // timing ablation: no stores (results are garbage)
+            asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+          } else {
+            store4<OUT>(D, ldd, m, n, v);
+          }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_256_p8: persistent form of the 8-phase kernel.  One workgroup per CU walks its list of output
+// tiles; the (tile, K-tile) steps form ONE continuous pipeline, so the LDS-DMA prefetch of the next
+// tile's first K-tiles is already in flight while the current tile's accumulators are converted and
+// stored, and the stores drain behind the next tile's MFMAs (they are never waited for: the four waits
+// after an epilogue use vmcnt(8 + 16 stores)).
+// Ownership is contiguous per wave (the half-tiles are row GATHERS, free with per-lane LDS-DMA sources):
+//   wave (wr, wc) owns rows 128*wr + 64*mh + [0,64) and columns 64*wc + 32*nh + [0,32), i.e. a 128x64
+//   block whose rows are whole 128-B lines of the bf16 output.  In the epilogue the two 4-column pieces
+//   a lane holds per (mh, i, nh) are widened to 8 contiguous columns with v_permlane16_swap and stored
+//   as one dwordx4 (16 rows x 64 B per instruction, 16 stores per wave and tile).
+constexpr int kEpiStores = 16;
+
+// rows of half-tile piece p (16w + 8i + lr) -> row inside the 256-row tile
+__device__ __forceinline__ int a_half_row(int h, int local) { return (local >> 6) * 128 + h * 64 + (local & 63); }
+__device__ __forceinline__ int b_half_row(int h, int local) { return (local >> 5) * 64 + h * 32 + (local & 31); }
+
+// LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... offen lds): SGPR resource + per-lane 32-bit
+// voffset (constant for the whole kernel) + uniform soffset per stage -> no per-stage VALU address math.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ void stage2(rsrc_t rs, const int (&voff)[2], int soff, uint8_t* lds_half, int wave) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds_half + (wave * 2 + i) * 1024), 16, voff[i], soff, 0, 0);
+}
+
+// Requires K % 256 == 0 (an even number of K-tiles, so every tile starts on LDS buffer 0) and
+// operand / output footprints < 2^31 bytes (32-bit buffer offsets); the host dispatcher checks both.
+template <int FA, int FB, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
+                                                      uint16_t* __restrict__ D, const float* __restrict__ sa_inv,
+                                                      const float* __restrict__ sb_inv, int K, int lda, int ldb,
+                                                      int ldd, int tiles_m, int tiles_n, int a_bytes, int b_bytes,
+                                                      int d_bytes) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int ntiles = tiles_m * tiles_n;
+  const int G = gridDim.x;
+  const int bid = blockIdx.x;
+  const int my_tiles = (ntiles - bid + G - 1) / G;  // tiles bid, bid + G, ...
+  const int nk = K / BK;
+  const float alpha = (*sa_inv) * (*sb_inv);
+  const rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
+  const rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
+  const rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)D, 0, d_bytes, 0x00020000);
+  v4f acc[2][4][2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[a][i][b][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+  // per-lane staging offsets (half h = 0; h = 1 adds a uniform 64*lda / 32*ldb)
+  int a_voff[2], b_voff[2];
+  {
+    const int lr = lane >> 3, lc = lane & 7;
+    const int chunk = (lc ^ swz_f(lr)) * 16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int local = (wave * 2 + i) * 8 + lr;
+      a_voff[i] = a_half_row(0, local) * lda + chunk;
+      b_voff[i] = b_half_row(0, local) * ldb + chunk;
+    }
+  }
+  const int a_h1 = 64 * lda, b_h1 = 32 * ldb;
+
+  // pipeline cursors (wave-uniform byte offsets of the (tile, K-tile) of step s+1 / s+2, clamped to the last step)
+  const int total = my_tiles * nk;
+  auto tile_origin = [&](int ti, int& oa, int& ob) {
+    int tm, tn;
+    tile_of_block(bid + ti * G, ntiles, tiles_m, tiles_n, tm, tn);
+    oa = tm * BM * lda;
+    ob = tn * BN * ldb;
+  };
+  int oa_1, ob_1, oa_2, ob_2, ti_1 = 0, kt_1 = 0, ti_2 = 0, kt_2 = 0;
+  int oa_0, ob_0;
+  tile_origin(0, oa_0, ob_0);
+  oa_1 = oa_2 = oa_0;
+  ob_1 = ob_2 = ob_0;
+  auto advance = [&](int& ti, int& kt, int& oa, int& ob, int step) {
+    if (step < total) {
+      if (++kt == nk) {
+        kt = 0;
+        ++ti;
+        tile_origin(ti, oa, ob);
+      }
+    }
+  };
+  advance(ti_1, kt_1, oa_1, ob_1, 1);
+  ti_2 = ti_1; kt_2 = kt_1; oa_2 = oa_1; ob_2 = ob_1;
+  advance(ti_2, kt_2, oa_2, ob_2, 2);
+
+  uint8_t* const buf0 = lds;
+  uint8_t* const buf1 = lds + kBufBytes;
+  // prologue: step 0 complete, (step 1: A0, B0) in flight
+  stage2(rsA, a_voff, oa_0, buf0 + kOffA0, wave);
+  stage2(rsB, b_voff, ob_0, buf0 + kOffB0, wave);
+  stage2(rsB, b_voff, ob_0 + b_h1, buf0 + kOffB1, wave);
+  stage2(rsA, a_voff, oa_0 + a_h1, buf0 + kOffA1, wave);
+  stage2(rsA, a_voff, oa_1 + kt_1 * BK, buf1 + kOffA0, wave);
+  stage2(rsB, b_voff, ob_1 + kt_1 * BK, buf1 + kOffB0, wave);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if (wr == 1) __builtin_amdgcn_s_barrier();
+
+  v8i af[4], b0f[2], b1f[2];
+  int s = 0;  // current step
+  // one K-tile = 4 phases.  `after_epi` (uniform): this is the first K-tile behind an epilogue, so the 16 stores
+  // sit between the awaited loads and the younger ones -> wait with vmcnt(8 + 16).
+#define MI_WAIT_SYNC(after_epi)                                        \
+  if (after_epi) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");     \
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                \
+  __builtin_amdgcn_s_barrier();                                        \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   \
+  __builtin_amdgcn_sched_barrier(0);                                   \
+  __builtin_amdgcn_s_setprio(1);
+#define MI_PIN8(EXPR)                                                  \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                        \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(EXPR));
+  auto ktile = [&](uint8_t* cur, uint8_t* oth, bool after_epi) {
+    const int sa1 = oa_1 + kt_1 * BK, sb1 = ob_1 + kt_1 * BK;
+    const int sa2 = oa_2 + kt_2 * BK, sb2 = ob_2 + kt_2 * BK;
+    // ---- phase 0
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b0f[j] = read_frag(cur + kOffB0, wc * 2 + j, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = read_frag(cur + kOffA0, wr * 4 + i, lane);
+    stage2(rsB, b_voff, sb1 + b_h1, oth + kOffB1, wave);
+    MI_WAIT_SYNC(after_epi)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[0][i][0][j] = mfma_ba<FA, FB>(af[i], b0f[j], acc[0][i][0][j], kUnitScale, kUnitScale);
+    MI_PIN8(acc[0][i][0][j])
+    MI_PHASE_END();
+    // ---- phase 1
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b1f[j] = read_frag(cur + kOffB1, wc * 2 + j, lane);
+    stage2(rsA, a_voff, sa1 + a_h1, oth + kOffA1, wave);
+    MI_WAIT_SYNC(after_epi)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[0][i][1][j] = mfma_ba<FA, FB>(af[i], b1f[j], acc[0][i][1][j], kUnitScale, kUnitScale);
+    MI_PIN8(acc[0][i][1][j])
+    MI_PHASE_END();
+    // ---- phase 2
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = read_frag(cur + kOffA1, wr * 4 + i, lane);
+    stage2(rsA, a_voff, sa2, cur + kOffA0, wave);
+    MI_WAIT_SYNC(after_epi)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[1][i][1][j] = mfma_ba<FA, FB>(af[i], b1f[j], acc[1][i][1][j], kUnitScale, kUnitScale);
+    MI_PIN8(acc[1][i][1][j])
+    MI_PHASE_END();
+    // ---- phase 3
+    stage2(rsB, b_voff, sb2, cur + kOffB0, wave);
+    MI_WAIT_SYNC(after_epi)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[1][i][0][j] = mfma_ba<FA, FB>(af[i], b0f[j], acc[1][i][0][j], kUnitScale, kUnitScale);
+    MI_PIN8(acc[1][i][0][j])
+    MI_PHASE_END();
+    // cursors follow the step
+    ++s;
+    advance(ti_1, kt_1, oa_1, ob_1, s + 1);
+    advance(ti_2, kt_2, oa_2, ob_2, s + 2);
+  };
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int ecol = (fq & 1) * 16 + (fq >> 1) * 8;  // column of this lane's 8-wide piece after the permlane16 swap
+  const int d_voff = ((wr * 128 + fr) * ldd + wc * 64 + ecol) * 2;  // bytes, within the tile
+  auto epilogue = [&](int ti) {
+    int tm, tn;
+    tile_of_block(bid + ti * G, ntiles, tiles_m, tiles_n, tm, tn);
+    const int d_tile = (tm * BM * ldd + tn * BN) * 2;  // uniform, bytes
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          v4f v0 = acc[a][i][b][0] * alpha, v1 = acc[a][i][b][1] * alpha;
+          u32 p0x = pack_bf16x2(v0[0], v0[1]), p0y = pack_bf16x2(v0[2], v0[3]);
+          u32 p1x = pack_bf16x2(v1[0], v1[1]), p1y = pack_bf16x2(v1[2], v1[3]);
+          auto sx = __builtin_amdgcn_permlane16_swap(p0x, p1x, false, false);
+          auto sy = __builtin_amdgcn_permlane16_swap(p0y, p1y, false, false);
+          v4i o = {(int)sx[0], (int)sy[0], (int)sx[1], (int)sy[1]};
+          if (ABL == 1) {
+            asm volatile("" ::"v"(o));
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)o, rsD, d_voff, d_tile + ((a * 64 + i * 16) * ldd + b * 32) * 2, 0);
+            // hipcc (ROCm 7.2) lets the next VALU overwrite the data registers of this 16-byte store (SGPR-offset form)
+            // with no wait state: lanes 12-15 of every 16-lane row then stored the NEXT block's unconverted fp32
+            // (seen on MI355X, tools/debug_gemm.py).  Keep the registers live across the required wait states.
+            asm volatile("s_nop 1" ::"v"(o) : "memory");
+          }
+          acc[a][i][b][0] = (v4f){0.f, 0.f, 0.f, 0.f};
+          acc[a][i][b][1] = (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+  };
+
+  int kt = 0, ti = 0;
+  for (int pair = 0; pair < total / 2; ++pair) {
+    ktile(buf0, buf1, kt == 0 && ti > 0);
+    ktile(buf1, buf0, false);
+    kt += 2;
+    if (kt == nk) {
+      epilogue(ti);
+      kt = 0;
+      ++ti;
+    }
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef MI_WAIT_SYNC
+#undef MI_PIN8
+}
+
+static int num_cus() {
+  static int n = 0;  // benign race: every thread computes the same value
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
+}
+
 template <int FA, int FB, int OUT>
 static int launch_fmt(const void* A, const void* B, void* D, const float* sa_inv, const float* sb_inv,
                       const void* SA, const void* SB, const void* bias, int64_t M, int64_t N, int64_t K,
@@ -427,6 +686,23 @@ static int launch_fmt(const void* A, const void* B, void* D, const float* sa_inv
   } else if (algo == 3 && !mx) {
     int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
     hipLaunchKernelGGL((gemm_256_8ph<FA, FB, OUT>), dim3(tiles_m * tiles_n), dim3(512), 0, st, a, b, D, sa_inv, sb_inv,
+                       bp, (int)M, (int)N, (int)K, lda, ldb, ldd, tiles_m, tiles_n);
+  } else if ((algo == 4 || algo == 15) && !mx) {
+    int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
+    int grid = tiles_m * tiles_n < num_cus() ? tiles_m * tiles_n : num_cus();
+    if (algo == 4)
+      hipLaunchKernelGGL((gemm_256_p8<FA, FB, 0>), dim3(grid), dim3(512), 0, st, a, b, (uint16_t*)D, sa_inv, sb_inv, (int)K,
+                         (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb), (int)(M * ldd * 2));
+    else
+      hipLaunchKernelGGL((gemm_256_p8<FA, FB, 1>), dim3(grid), dim3(512), 0, st, a, b, (uint16_t*)D, sa_inv, sb_inv, (int)K,
+                         (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb), (int)(M * ldd * 2));
+  } else if (algo == 13 && !mx) {
+    int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
+    hipLaunchKernelGGL((gemm_256_8ph<FA, FB, OUT, 1>), dim3(tiles_m * tiles_n), dim3(512), 0, st, a, b, D, sa_inv, sb_inv,
+                       bp, (int)M, (int)N, (int)K, lda, ldb, ldd, tiles_m, tiles_n);
+  } else if (algo == 14 && !mx) {  // diagnostic: `bias` is a u64[2 * tiles] debug buffer (cycles, 100 MHz ticks)
+    int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
+    hipLaunchKernelGGL((gemm_256_8ph<FA, FB, OUT, 2>), dim3(tiles_m * tiles_n), dim3(512), 0, st, a, b, D, sa_inv, sb_inv,
                        bp, (int)M, (int)N, (int)K, lda, ldb, ldd, tiles_m, tiles_n);
   } else {
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
@@ -469,11 +745,22 @@ static int check_common(const char* who, const void* A, const void* B, void* D, 
   return MI_OK;
 }
 
-static int pick_algo(int algo, int64_t M, int64_t N, int64_t K, const char* who) {
+static int pick_algo(int algo, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int out, bool has_bias,
+                     const char* who) {
   const bool fast_ok = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && M > 0 && N > 0 && K > 0;
-  if (algo == 0) return fast_ok ? 2 : 1;
+  // persistent kernel: even K-tile count, bf16 output without bias, 32-bit buffer offsets
+  const bool p8_ok = fast_ok && (K % (2 * BK) == 0) && out == 0 && !has_bias && M * lda < (1LL << 31) &&
+                     N * ldb < (1LL << 31) && M * ldd * 2 < (1LL << 31);
+  if (algo == 4 || algo == 15) {
+    if (!p8_ok) {
+      set_error("%s: algo %d needs M,N %% 256 == 0, K %% 256 == 0, bf16 output, no bias, operands < 2 GiB", who, algo);
+      return MI_ERR_SHAPE;
+    }
+    return algo;
+  }
+  if (algo == 0) return p8_ok ? 4 : (fast_ok ? 3 : 1);
   if (algo == 1) return 1;
-  if (algo == 2 || algo == 3) {
+  if (algo == 2 || algo == 3 || algo == 13 || algo == 14) {
     if (!fast_ok) {
       set_error("%s: algo %d needs M,N %% 256 == 0 and K %% 128 == 0", who, algo);
       return MI_ERR_SHAPE;
@@ -493,7 +780,7 @@ extern "C" int mi_gemm_fp8(const void* A, const void* B, void* D, const float* s
   if (rc != MI_OK) return rc;
   MI_CHECK_ARG(sa_inv && sb_inv, "mi_gemm_fp8: null scale pointer");
   if (M == 0 || N == 0) return MI_OK;
-  int a = mi::pick_algo(algo, M, N, K, "mi_gemm_fp8");
+  int a = mi::pick_algo(algo, M, N, K, lda, ldb, ldd, out_dtype, bias_bf16 != nullptr, "mi_gemm_fp8");
   if (a < 0) return a;
   return mi::dispatch(A, B, D, sa_inv, sb_inv, nullptr, nullptr, bias_bf16, M, N, K, lda, ldb, ldd, fmt_a, fmt_b,
                       out_dtype, a, false, (hipStream_t)stream);

@@ -49,6 +49,42 @@ def main():
                     tf = 2.0 * m * n * k / t / 1e12
                     print(f"gemm {name:4s} {kind:5s} {m:6d}x{n:6d}x{k:6d} algo {algo}: {t*1e6:9.1f} us {tf:8.1f} TFLOP/s "
                           f"({tf/5000*100:5.1f}% of 5 PF)", flush=True)
+    if "ksweep" in args.which:
+        # fixed 8192x8192 output (1024 tiles = 4 full rounds), K sweep: slope = mainloop cost per K-tile, intercept = per-tile overhead
+        for algo in [int(x) for x in args.algos.split(",")]:
+            for k in (256, 512, 1024, 2048, 4096, 8192):
+                m = n = 8192
+                a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
+                out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+                t = time_fn(lambda: ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=algo), args.iters)
+                print(f"ksweep algo {algo} K={k:5d}: {t*1e6:9.1f} us  per-round {t*1e6/4:8.1f} us  {2.0*m*n*k/t/1e12:8.1f} TFLOP/s", flush=True)
+    if "clock" in args.which:
+        from llm_fp8_amd import _lib
+        lib = _lib.load()
+        m = n = 8192
+        for fill in ("random", "zeros"):
+            for k in (2048, 8192):
+                a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
+                if fill == "zeros":
+                    a.zero_(); b.zero_()
+                out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+                dbg = torch.zeros((1024, 2), dtype=torch.int64, device=dev)
+                st = torch.cuda.current_stream().cuda_stream
+                def run(algo, bias_ptr):
+                    rc = lib.mi_gemm_fp8(a.data_ptr(), b.data_ptr(), out.data_ptr(), one.data_ptr(), one.data_ptr(), bias_ptr,
+                                         m, n, k, k, k, n, 0, 0, 0, algo, st)
+                    assert rc == 0, lib.mi_last_error()
+                for _ in range(200):  # heat up
+                    run(13, None)
+                run(14, dbg.data_ptr())
+                torch.cuda.synchronize()
+                d = dbg.cpu().double()
+                cyc, ticks = d[:, 0], d[:, 1]
+                clk = (cyc / ticks * 100.0)  # MHz
+                t = time_fn(lambda: run(13, None), args.iters)
+                print(f"clock {fill:6s} K={k}: loop cycles/K-tile median {float((cyc / (k/128)).median()):8.1f} "
+                      f"in-kernel clock median {float(clk.median()):7.1f} MHz (min {float(clk.min()):.0f} max {float(clk.max()):.0f}); "
+                      f"no-store kernel {t*1e6:8.1f} us = {2.0*m*n*k/t/1e12:7.1f} TFLOP/s", flush=True)
     if "cast" in args.which:
         for (R, C) in ((8192, 3072), (8192, 16384), (16384, 3072), (8192, 8192)):
             x = torch.randn((R, C), device=dev, dtype=torch.float32, generator=g).to(torch.bfloat16)
