@@ -110,6 +110,34 @@ int mi_gemm_mxfp8(const void* A, const void* SA, const void* B, const void* SB, 
                   const void* bias_bf16, int64_t M, int64_t N, int64_t K, int fmt_a, int fmt_b,
                   int out_dtype, int algo, void* stream);
 
+/*
+ * RoPE fused with the q/k/v split of the QKV projection output  [TE applies a fused RoPE kernel between
+ * layernorm_qkv and the attention core on the reference path, te_llama.py:65-66,77].
+ *   forward  (backward = 0): q, k, v <- fused [rows, (nq + 2 nkv) * D]; q, k heads rotated by +theta(row % seq)
+ *   backward (backward = 1): fused gradient <- dq, dk, dv with the conjugate rotation
+ * out1 = x1 cos - x2 sin, out2 = x2 cos + x1 sin over the two halves of a head (non-interleaved);
+ * cos_tab / sin_tab: fp32 [>= seq, D/2]; math in fp32, one bf16 rounding.
+ */
+int mi_rope_qkv(void* fused_bf16, void* q_bf16, void* k_bf16, void* v_bf16, const float* cos_tab,
+                const float* sin_tab, int64_t rows, int64_t seq, int n_q_heads, int n_kv_heads, int head_dim,
+                int backward, void* stream);
+
+/*
+ * K10  SwiGLU fused with the FP8 cast of fc2's input  [TE LayerNormMLP activation="swiglu", te_llama.py:58-63].
+ *   act[r,c] = silu(h[r,c]) * h[r,F+c] in fp32, c in [0,F);  y = sat_cast(act * *scale), yT its transpose,
+ *   *amax = max(*amax, max|act|).  h: bf16 [rows, 2F] (gate | up).  rows, F multiples of 8.
+ */
+int mi_swiglu_cast(const void* h_bf16, void* y_fp8, void* yT_fp8, const float* scale, float* amax,
+                   int64_t rows, int64_t F, int fmt, void* stream);
+
+/*
+ * K10 backward: dh = [dact * dsilu(g) * u | dact * silu(g)] in fp32 -> FP8 [rows, 2F] (+ transpose) + amax.
+ * colsum (nullable): fp32 [ceil(rows/128), 2F] per-row-block column sums of dh in a fixed order (the caller adds
+ * the row blocks to get the fc1 bias gradient bitwise reproducibly).
+ */
+int mi_dswiglu_cast(const void* h_bf16, const void* dact_bf16, void* y_fp8, void* yT_fp8, const float* scale,
+                    float* amax, float* colsum, int64_t rows, int64_t F, int fmt, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,263 @@
+// HBM-bound fusions on either side of the FP8 GEMMs (SURVEY.md 8f "next" rows):
+//   mi_rope_qkv         fwd: split the fused QKV GEMM output into q, k, v and rotate q, k (RoPE) in the same pass;
+//                       bwd: merge dq, dk, dv back into the fused gradient with the conjugate rotation --
+//                       one launch each instead of the split/mul/neg/cat/add chain (TE uses a fused RoPE
+//                       kernel at this point of the reference path, te_llama.py:77).
+//   mi_swiglu_cast      K10 fwd: act = silu(h[:, :F]) * h[:, F:] in fp32 -> FP8 (+ transposed copy) + amax,
+//                       without materialising the bf16 activation (te_llama.py:62 activation="swiglu").
+//   mi_dswiglu_cast     K10 bwd: dh = [dact * dsilu(g) * u | dact * silu(g)] in fp32 -> FP8 (+T) + amax,
+//                       plus deterministic per-row-block column sums for the fc1 bias gradient.
+#include "mi_common.h"
+
+namespace mi {
+
+// ------------------------------------------------------------------------------------------------ RoPE
+// fused: [rows, W] bf16 with columns q (nq heads) | k (nk heads) | v (nk heads), head size D.
+// DIR 0 (forward):  q, k, v (separate contiguous [rows, heads*D]) <- fused, q/k rotated by +theta(pos), v copied
+// DIR 1 (backward): fused gradient <- dq, dk, dv, q/k parts rotated by -theta(pos)
+// Row r has position (r % seq) (bshd).  cos/sin: [>= seq, D/2] fp32.
+// out1 = x1*c - x2*s, out2 = x2*c + x1*s with x1/x2 the two halves of a head (TE's non-interleaved RoPE).
+template <int DIR>
+__global__ __launch_bounds__(256) void rope_qkv_kernel(uint16_t* __restrict__ fused, uint16_t* __restrict__ q,
+                                                       uint16_t* __restrict__ k, uint16_t* __restrict__ v,
+                                                       const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                       int rows, int seq, int nq, int nk, int D) {
+  const int half = D >> 1;
+  const int vph = half >> 3;  // 8-element vector pairs per head
+  const int W = (nq + 2 * nk) * D;
+  const int rot_items = (nq + nk) * vph;    // per row
+  const int cpy_items = (nk * D) >> 3;      // per row
+  const int per_row = rot_items + cpy_items;
+  const int64_t items = (int64_t)rows * per_row;
+  const float sgn = DIR == 0 ? 1.0f : -1.0f;
+  for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = it / per_row;
+    const int w = (int)(it - r * per_row);
+    uint16_t* frow = fused + r * W;
+    if (w < rot_items) {
+      const int hd = w / vph, vv = w - hd * vph;
+      uint16_t* sep = hd < nq ? q + (r * nq + hd) * D : k + (r * nk + (hd - nq)) * D;
+      uint16_t* f1 = frow + hd * D + vv * 8;
+      uint16_t* s1 = sep + vv * 8;
+      const uint16_t* in1 = DIR == 0 ? f1 : s1;
+      uint16_t* out1 = DIR == 0 ? s1 : f1;
+      const v4i a = *reinterpret_cast<const v4i*>(in1), b = *reinterpret_cast<const v4i*>(in1 + half);
+      const int pos = (int)(r % seq);
+      const float* cp = cosT + (int64_t)pos * half + vv * 8;
+      const float* sp = sinT + (int64_t)pos * half + vv * 8;
+      float c[8], sn[8];
+      *reinterpret_cast<v4f*>(c) = *reinterpret_cast<const v4f*>(cp);
+      *reinterpret_cast<v4f*>(c + 4) = *reinterpret_cast<const v4f*>(cp + 4);
+      *reinterpret_cast<v4f*>(sn) = *reinterpret_cast<const v4f*>(sp);
+      *reinterpret_cast<v4f*>(sn + 4) = *reinterpret_cast<const v4f*>(sp + 4);
+      v4i o1, o2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32 wa = (u32)a[j], wb = (u32)b[j];
+        const float x1l = __uint_as_float(wa << 16), x1h = __uint_as_float(wa & 0xFFFF0000u);
+        const float x2l = __uint_as_float(wb << 16), x2h = __uint_as_float(wb & 0xFFFF0000u);
+        const float cl = c[2 * j], ch = c[2 * j + 1], sl = sgn * sn[2 * j], sh = sgn * sn[2 * j + 1];
+        o1[j] = (int)pack_bf16x2(x1l * cl - x2l * sl, x1h * ch - x2h * sh);
+        o2[j] = (int)pack_bf16x2(x2l * cl + x1l * sl, x2h * ch + x1h * sh);
+      }
+      *reinterpret_cast<v4i*>(out1) = o1;
+      *reinterpret_cast<v4i*>(out1 + half) = o2;
+    } else {
+      const int cv = w - rot_items;
+      uint16_t* fp = frow + (nq + nk) * D + cv * 8;
+      uint16_t* sp2 = v + r * (int64_t)(nk * D) + cv * 8;
+      if (DIR == 0) *reinterpret_cast<v4i*>(sp2) = *reinterpret_cast<const v4i*>(fp);
+      else *reinterpret_cast<v4i*>(fp) = *reinterpret_cast<const v4i*>(sp2);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ SwiGLU (+cast)
+__device__ __forceinline__ float sigmoidf_(float g) { return 1.0f / (1.0f + __expf(-g)); }
+
+// Same tiling as cast_amax_kernel: 128x128 output tile per workgroup, 8x8 block per lane.
+// MODE 0 (fwd):  in = h [rows, 2F];            val(r,c) = silu(h[r,c]) * h[r,F+c],   c in [0,F)  -> out [rows, F]
+// MODE 1 (bwd):  in = h [rows, 2F], d [rows,F]; val(r,c) = d[r,c]*dsilu(g)*u (c < F) | d[r,c-F]*silu(g) (c >= F) -> out [rows, 2F]
+//               colsum[(tile_r), c] = sum over the tile's 128 rows of val (fp32), for the fc1 bias gradient.
+template <int FMT, int MODE, bool WRITE_Y, bool WRITE_T>
+__global__ __launch_bounds__(256) void swiglu_cast_kernel(const uint16_t* __restrict__ h, const uint16_t* __restrict__ d,
+                                                          uint8_t* __restrict__ y, uint8_t* __restrict__ yT,
+                                                          const float* __restrict__ scale_p, float* amax_out,
+                                                          float* __restrict__ colsum, int rows, int F, int tiles_c) {
+  __shared__ float s_amax[4];
+  __shared__ float s_col[2][128];
+  const int ocols = MODE == 0 ? F : 2 * F;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile_r = blockIdx.x / tiles_c, tile_c = blockIdx.x % tiles_c;
+  const int r0 = tile_r * 128 + (wave >> 1) * 64 + (lane >> 3) * 8;
+  const int c0 = tile_c * 128 + (wave & 1) * 64 + (lane & 7) * 8;
+  const float scale = *scale_p;
+  float amax = 0.0f;
+  float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool active = (r0 < rows) && (c0 < ocols);
+  if (active) {
+    // F is a multiple of 8, so an 8-wide block is entirely in the gate half or entirely in the up half
+    const bool up_half = (MODE == 1) && (c0 >= F);
+    const int cg = up_half ? c0 - F : c0;  // column inside the gate / d tensors
+    u32 lo[8], hi[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int64_t r = r0 + i;
+      const v4i gv = *reinterpret_cast<const v4i*>(h + r * 2 * F + cg);
+      const v4i uv = *reinterpret_cast<const v4i*>(h + r * 2 * F + F + cg);
+      v4i dv = {0, 0, 0, 0};
+      if (MODE == 1) dv = *reinterpret_cast<const v4i*>(d + r * F + cg);
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32 wg = (u32)gv[j], wu = (u32)uv[j], wd = (u32)dv[j];
+        const float g2[2] = {__uint_as_float(wg << 16), __uint_as_float(wg & 0xFFFF0000u)};
+        const float u2[2] = {__uint_as_float(wu << 16), __uint_as_float(wu & 0xFFFF0000u)};
+        const float d2[2] = {__uint_as_float(wd << 16), __uint_as_float(wd & 0xFFFF0000u)};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float sg = sigmoidf_(g2[e]);
+          float v;
+          if (MODE == 0) v = g2[e] * sg * u2[e];
+          else if (!up_half) v = d2[e] * u2[e] * (sg * (1.0f + g2[e] * (1.0f - sg)));
+          else v = d2[e] * (g2[e] * sg);
+          f[2 * j + e] = v;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        amax = fmaxf(amax, (f[j] != f[j]) ? 0.0f : fabsf(f[j]));
+        if (MODE == 1) csum[j] += f[j];
+      }
+      lo[i] = cvt4_fp8<FMT>(f[0] * scale, f[1] * scale, f[2] * scale, f[3] * scale);
+      hi[i] = cvt4_fp8<FMT>(f[4] * scale, f[5] * scale, f[6] * scale, f[7] * scale);
+    }
+    if (WRITE_Y) {
+      uint8_t* dst = y + (int64_t)r0 * ocols + c0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<uint2*>(dst + (int64_t)i * ocols) = make_uint2(lo[i], hi[i]);
+    }
+    if (WRITE_T) {
+      u32 a[4], b[4], c[4], dd[4];
+      transpose4x4(lo[0], lo[1], lo[2], lo[3], a[0], a[1], a[2], a[3]);
+      transpose4x4(lo[4], lo[5], lo[6], lo[7], b[0], b[1], b[2], b[3]);
+      transpose4x4(hi[0], hi[1], hi[2], hi[3], c[0], c[1], c[2], c[3]);
+      transpose4x4(hi[4], hi[5], hi[6], hi[7], dd[0], dd[1], dd[2], dd[3]);
+      uint8_t* dst = yT + (int64_t)c0 * rows + r0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<uint2*>(dst + (int64_t)j * rows) = make_uint2(a[j], b[j]);
+        *reinterpret_cast<uint2*>(dst + (int64_t)(j + 4) * rows) = make_uint2(c[j], dd[j]);
+      }
+    }
+  }
+  if (MODE == 1 && colsum != nullptr) {
+    // reduce the 8 row-blocks of a wave (lanes differing in lane>>3), then the 2 wave-rows through LDS:
+    // a fixed order, so the bias gradient is bitwise reproducible
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = csum[j];
+      v += __shfl_xor(v, 8);
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      csum[j] = v;
+    }
+    if ((lane >> 3) == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s_col[wave >> 1][(wave & 1) * 64 + (lane & 7) * 8 + j] = csum[j];
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int c = tile_c * 128 + tid;
+      if (c < ocols) colsum[(int64_t)tile_r * ocols + c] = s_col[0][tid] + s_col[1][tid];
+    }
+  }
+  if (amax_out != nullptr) {
+    amax = wave_max(amax);
+    if (lane == 0) s_amax[wave] = amax;
+    __syncthreads();
+    if (tid == 0) {
+      float m = fmaxf(fmaxf(s_amax[0], s_amax[1]), fmaxf(s_amax[2], s_amax[3]));
+      if (m > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(amax_out), __float_as_uint(m));
+    }
+  }
+}
+
+template <int FMT, int MODE>
+static int launch_swiglu(const void* h, const void* d, void* y, void* yT, const float* scale, float* amax, float* colsum,
+                         int64_t rows, int64_t F, hipStream_t st) {
+  const int64_t ocols = MODE == 0 ? F : 2 * F;
+  const int tiles_r = (int)((rows + 127) / 128), tiles_c = (int)((ocols + 127) / 128);
+  dim3 grid((unsigned)(tiles_r * tiles_c)), block(256);
+  const uint16_t *hp = (const uint16_t*)h, *dp = (const uint16_t*)d;
+  uint8_t *yp = (uint8_t*)y, *tp = (uint8_t*)yT;
+  if (y && yT)
+    hipLaunchKernelGGL((swiglu_cast_kernel<FMT, MODE, true, true>), grid, block, 0, st, hp, dp, yp, tp, scale, amax, colsum, (int)rows, (int)F, tiles_c);
+  else if (y)
+    hipLaunchKernelGGL((swiglu_cast_kernel<FMT, MODE, true, false>), grid, block, 0, st, hp, dp, yp, tp, scale, amax, colsum, (int)rows, (int)F, tiles_c);
+  else
+    hipLaunchKernelGGL((swiglu_cast_kernel<FMT, MODE, false, true>), grid, block, 0, st, hp, dp, yp, tp, scale, amax, colsum, (int)rows, (int)F, tiles_c);
+  MI_CHECK_LAUNCH("mi_swiglu_cast launch");
+  return MI_OK;
+}
+
+}  // namespace mi
+
+extern "C" int mi_rope_qkv(void* fused_bf16, void* q_bf16, void* k_bf16, void* v_bf16, const float* cos_tab,
+                           const float* sin_tab, int64_t rows, int64_t seq, int n_q_heads, int n_kv_heads, int head_dim,
+                           int backward, void* stream) {
+  MI_CHECK_ARG(fused_bf16 && q_bf16 && k_bf16 && v_bf16 && cos_tab && sin_tab, "mi_rope_qkv: null pointer");
+  MI_CHECK_ARG(rows >= 0 && seq > 0 && n_q_heads > 0 && n_kv_heads > 0, "mi_rope_qkv: bad shape");
+  MI_CHECK_ARG(head_dim > 0 && head_dim % 16 == 0, "mi_rope_qkv: head_dim must be a multiple of 16");
+  MI_CHECK_ARG(((uintptr_t)fused_bf16 % 16) == 0 && ((uintptr_t)q_bf16 % 16) == 0 && ((uintptr_t)k_bf16 % 16) == 0 &&
+                   ((uintptr_t)v_bf16 % 16) == 0 && ((uintptr_t)cos_tab % 16) == 0 && ((uintptr_t)sin_tab % 16) == 0,
+               "mi_rope_qkv: pointers must be 16-byte aligned");
+  MI_CHECK_ARG(rows < (1LL << 31), "mi_rope_qkv: too many rows");
+  if (rows == 0) return MI_OK;
+  const int64_t per_row = (int64_t)(n_q_heads + n_kv_heads) * (head_dim / 16) + (int64_t)n_kv_heads * head_dim / 8;
+  int64_t blocks = (rows * per_row + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (backward)
+    hipLaunchKernelGGL(mi::rope_qkv_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (uint16_t*)fused_bf16,
+                       (uint16_t*)q_bf16, (uint16_t*)k_bf16, (uint16_t*)v_bf16, cos_tab, sin_tab, (int)rows, (int)seq, n_q_heads,
+                       n_kv_heads, head_dim);
+  else
+    hipLaunchKernelGGL(mi::rope_qkv_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (uint16_t*)fused_bf16,
+                       (uint16_t*)q_bf16, (uint16_t*)k_bf16, (uint16_t*)v_bf16, cos_tab, sin_tab, (int)rows, (int)seq, n_q_heads,
+                       n_kv_heads, head_dim);
+  MI_CHECK_LAUNCH("mi_rope_qkv launch");
+  return MI_OK;
+}
+
+static int swiglu_common_check(const char* who, const void* h, const void* y, const void* yT, const float* scale,
+                               int64_t rows, int64_t F, int fmt) {
+  MI_CHECK_ARG(h && scale, "%s: null input", who);
+  MI_CHECK_ARG(y || yT, "%s: at least one of y, yT must be non-null", who);
+  MI_CHECK_ARG(rows >= 0 && F >= 0 && rows % 8 == 0 && F % 8 == 0, "%s: rows and F must be multiples of 8", who);
+  MI_CHECK_ARG(rows < (1LL << 31) && 2 * F < (1LL << 31), "%s: shape too large", who);
+  MI_CHECK_ARG(((uintptr_t)h % 16) == 0 && ((uintptr_t)y % 8) == 0 && ((uintptr_t)yT % 8) == 0, "%s: misaligned pointer", who);
+  MI_CHECK_ARG(fmt == MI_FMT_E4M3 || fmt == MI_FMT_E5M2, "%s: bad fmt %d", who, fmt);
+  return MI_OK;
+}
+
+extern "C" int mi_swiglu_cast(const void* h_bf16, void* y_fp8, void* yT_fp8, const float* scale, float* amax,
+                              int64_t rows, int64_t F, int fmt, void* stream) {
+  int rc = swiglu_common_check("mi_swiglu_cast", h_bf16, y_fp8, yT_fp8, scale, rows, F, fmt);
+  if (rc != MI_OK) return rc;
+  if (rows == 0 || F == 0) return MI_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (fmt == MI_FMT_E4M3) return mi::launch_swiglu<MI_FMT_E4M3, 0>(h_bf16, nullptr, y_fp8, yT_fp8, scale, amax, nullptr, rows, F, st);
+  return mi::launch_swiglu<MI_FMT_E5M2, 0>(h_bf16, nullptr, y_fp8, yT_fp8, scale, amax, nullptr, rows, F, st);
+}
+
+extern "C" int mi_dswiglu_cast(const void* h_bf16, const void* dact_bf16, void* y_fp8, void* yT_fp8, const float* scale,
+                               float* amax, float* colsum, int64_t rows, int64_t F, int fmt, void* stream) {
+  int rc = swiglu_common_check("mi_dswiglu_cast", h_bf16, y_fp8, yT_fp8, scale, rows, F, fmt);
+  if (rc != MI_OK) return rc;
+  MI_CHECK_ARG(dact_bf16 && ((uintptr_t)dact_bf16 % 16) == 0, "mi_dswiglu_cast: dact must be non-null and 16-byte aligned");
+  if (rows == 0 || F == 0) return MI_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (fmt == MI_FMT_E4M3)
+    return mi::launch_swiglu<MI_FMT_E4M3, 1>(h_bf16, dact_bf16, y_fp8, yT_fp8, scale, amax, colsum, rows, F, st);
+  return mi::launch_swiglu<MI_FMT_E5M2, 1>(h_bf16, dact_bf16, y_fp8, yT_fp8, scale, amax, colsum, rows, F, st);
+}

@@ -12,6 +12,7 @@ from typing import Optional
 import torch
 import torch.nn.functional as F
 
+from . import ops
 from .module import LayerNormLinear, Linear
 
 __all__ = ["RotaryPositionEmbedding", "apply_rotary_pos_emb", "DotProductAttention", "MultiheadAttention"]
@@ -56,6 +57,46 @@ def apply_rotary_pos_emb(t: torch.Tensor, freqs: torch.Tensor, tensor_format: st
     tr, tp = t[..., :rot], t[..., rot:]
     out = tr * cos + _rotate_half(tr) * sin
     return out if tp.shape[-1] == 0 else torch.cat((out, tp), dim=-1)
+
+
+_COS_SIN_CACHE = {}
+
+
+def _cos_sin_tables(freqs: torch.Tensor, seq: int):
+    """fp32 cos/sin [seq, D/2] of a TE angle table [s_max,1,1,D] (= cat(f, f)); cached per table and length."""
+    key = (freqs.data_ptr(), freqs.shape, seq, str(freqs.device))
+    hit = _COS_SIN_CACHE.get(key)
+    if hit is None:
+        half = freqs.shape[-1] // 2
+        f = freqs[:seq, 0, 0, :half].float()
+        hit = (torch.cos(f).contiguous(), torch.sin(f).contiguous())
+        if len(_COS_SIN_CACHE) > 16:
+            _COS_SIN_CACHE.clear()
+        _COS_SIN_CACHE[key] = hit
+    return hit
+
+
+class _RoPESplitFn(torch.autograd.Function):
+    """qkv [B,S,W] -> q [B,S,h,d], k, v [B,S,g,d] with RoPE on q, k: one HIP launch each way (mi_rope_qkv)."""
+
+    @staticmethod
+    def forward(ctx, qkv, cos, sin, n_q, n_kv, d):
+        B, S, W = qkv.shape
+        x = qkv.reshape(B * S, W)
+        x = x if x.is_contiguous() else x.contiguous()
+        q, k, v = ops.rope_qkv_forward(x, cos, sin, n_q, n_kv, d, S)
+        ctx.save_for_backward(cos, sin)
+        ctx.meta = (B, S, n_q, n_kv, d)
+        return q.view(B, S, n_q, d), k.view(B, S, n_kv, d), v.view(B, S, n_kv, d)
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        cos, sin = ctx.saved_tensors
+        B, S, n_q, n_kv, d = ctx.meta
+        T = B * S
+        g = ops.rope_qkv_backward(dq.reshape(T, n_q * d), dk.reshape(T, n_kv * d), dv.reshape(T, n_kv * d), cos, sin,
+                                  n_q, n_kv, d, S)
+        return g.view(B, S, -1), None, None, None, None, None
 
 
 class DotProductAttention(torch.nn.Module):
@@ -126,6 +167,12 @@ class MultiheadAttention(torch.nn.Module):
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 rotary_pos_emb=None, **_ignored) -> torch.Tensor:
         qkv = self.layernorm_qkv(hidden_states) if self.input_layernorm else self.qkv(hidden_states)
+        if (rotary_pos_emb is not None and not isinstance(rotary_pos_emb, (tuple, list)) and qkv.is_cuda
+                and qkv.dtype == torch.bfloat16 and self.qkv_format == "bshd" and self.d % 16 == 0
+                and rotary_pos_emb.shape[-1] == self.d):
+            cos, sin = _cos_sin_tables(rotary_pos_emb, qkv.shape[1])
+            q, k, v = _RoPESplitFn.apply(qkv, cos, sin, self.h, self.g, self.d)
+            return self.proj(self.core_attention(q, k, v, attention_mask))
         q, k, v = torch.split(qkv, self.split, dim=-1)
         a, b = qkv.shape[0], qkv.shape[1]
         q = q.reshape(a, b, self.h, self.d)

@@ -128,6 +128,67 @@ class _FP8LinearFn(torch.autograd.Function):
         return (dx, db, None, *dws)
 
 
+class _FP8SwiGLUMLPFn(torch.autograd.Function):
+    """fc1 (FP8) -> SwiGLU fused with the FP8 cast of fc2's input -> fc2 (FP8), delayed scaling: TE's LayerNormMLP
+    structure (te_llama.py:58-63).  The bf16 activation is never materialised; backward fuses dSwiGLU with the cast of
+    fc1's grad_output and returns the fc1 bias gradient from the same pass."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, spec: _GemmSpec):
+        x2 = _as_bf16_2d(x)
+        M, K = x2.shape
+        if M % 8 or K % 16:
+            raise RuntimeError(f"FP8 LayerNormMLP needs tokens % 8 == 0 and hidden % 16 == 0, got {M} x {K}")
+        mf, fmt = spec.meta_fwd, spec.fmt_fwd
+        need_dgrad = bool(ctx.needs_input_grad[0])
+        need_w = bool(ctx.needs_input_grad[1]) or bool(ctx.needs_input_grad[3])
+        bwd = need_dgrad or need_w
+        x8, x8t = ops.cast_amax(x2, mf.scale(0), mf.amax(0), fmt, want_t=need_w)
+        w1b = (w1 if w1.dtype == torch.bfloat16 else w1.to(torch.bfloat16)).contiguous()
+        w1_8, w1_8t = ops.cast_amax(w1b, mf.scale(1), mf.amax(1), fmt, want_t=bwd)
+        h = ops.gemm_fp8(x8, w1_8, mf.scale_inv(0), mf.scale_inv(1), fmt, fmt,
+                         bias=None if b1 is None else b1.to(torch.bfloat16).contiguous())
+        a8, a8t = ops.swiglu_cast(h, mf.scale(3), mf.amax(3), fmt, want_t=need_w)
+        w2b = (w2 if w2.dtype == torch.bfloat16 else w2.to(torch.bfloat16)).contiguous()
+        w2_8, w2_8t = ops.cast_amax(w2b, mf.scale(4), mf.amax(4), fmt, want_t=bwd)
+        y = ops.gemm_fp8(a8, w2_8, mf.scale_inv(3), mf.scale_inv(4), fmt, fmt,
+                         bias=None if b2 is None else b2.to(torch.bfloat16).contiguous())
+        ctx.saved_fp8 = (x8t, w1_8t, a8t, w2_8t, h if bwd else None, mf.scale_inv_snapshot() if bwd else None)
+        ctx.spec, ctx.x_shape, ctx.x_dtype = spec, x.shape, x.dtype
+        ctx.dtypes = (w1.dtype, None if b1 is None else b1.dtype, w2.dtype, None if b2 is None else b2.dtype)
+        ctx.need_dgrad, ctx.need_w = need_dgrad, need_w
+        return y.view(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        spec = ctx.spec
+        mb, fmt_f, fmt_b = spec.meta_bwd, spec.fmt_fwd, spec.fmt_bwd
+        x8t, w1_8t, a8t, w2_8t, h, sinv = ctx.saved_fp8
+        ctx.saved_fp8 = None
+        g2 = _as_bf16_2d(dy)
+        # fc2 backward (GEMM index 1: bwd slot 2)
+        g8, g8t = ops.cast_amax(g2, mb.scale(2), mb.amax(2), fmt_b, want_t=ctx.need_w)
+        dact = ops.gemm_fp8(g8, w2_8t, mb.scale_inv(2), sinv[4:5], fmt_b, fmt_f)
+        dw2 = ops.gemm_fp8(g8t, a8t, mb.scale_inv(2), sinv[3:4], fmt_b, fmt_f) if ctx.need_w else None
+        db2 = g2.sum(0, dtype=torch.float32).to(ctx.dtypes[3]) if ctx.dtypes[3] is not None else None
+        # dSwiGLU + cast of fc1's grad_output (GEMM index 0: bwd slot 0) + fc1 bias gradient
+        want_b1 = ctx.dtypes[1] is not None
+        dh8, dh8t, colsum = ops.dswiglu_cast(h, dact, mb.scale(0), mb.amax(0), fmt_b, want_y=ctx.need_dgrad,
+                                             want_t=ctx.need_w, want_colsum=want_b1)
+        db1 = colsum.sum(0).to(ctx.dtypes[1]) if want_b1 else None
+        dx = ops.gemm_fp8(dh8, w1_8t, mb.scale_inv(0), sinv[1:2], fmt_b, fmt_f) if ctx.need_dgrad else None
+        dw1 = ops.gemm_fp8(dh8t, x8t, mb.scale_inv(0), sinv[0:1], fmt_b, fmt_f) if ctx.need_w else None
+        if spec.trigger_bwd_update:
+            FP8GlobalStateManager.reduce_and_update_fp8_tensors(forward=False)
+        if dx is not None:
+            dx = dx.view(ctx.x_shape).to(ctx.x_dtype)
+        if dw1 is not None and dw1.dtype != ctx.dtypes[0]:
+            dw1 = dw1.to(ctx.dtypes[0])
+        if dw2 is not None and dw2.dtype != ctx.dtypes[2]:
+            dw2 = dw2.to(ctx.dtypes[2])
+        return dx, dw1, db1, dw2, db2, None
+
+
 class _FP8Module(torch.nn.Module):
     """Shared FP8 bookkeeping: lazily allocated meta windows, `_extra_state` (TE serialises its FP8
     metadata there; it ends up in `save_pretrained`, train_fp8.py:668-669)."""
@@ -356,6 +417,7 @@ class LayerNormMLP(_FP8Module):
         self.use_bias = bias
         self.fc1_bias = torch.nn.Parameter(torch.zeros(mult * ffn_hidden_size, dtype=dt, device=device)) if bias else None
         self.fc2_bias = torch.nn.Parameter(torch.zeros(hidden_size, dtype=dt, device=device)) if bias else None
+        self.fused_swiglu = True  # K10: SwiGLU fused with the FP8 cast (delayed scaling); False -> two Linears + torch ops
 
     def _norm(self, x):
         if self.normalization == "RMSNorm":
@@ -370,6 +432,9 @@ class LayerNormMLP(_FP8Module):
             return F.linear(self.act_fn(h), self.fc2_weight.to(ln.dtype),
                             None if self.fc2_bias is None else self.fc2_bias.to(ln.dtype))
         recipe, mf, mb, first = st
+        if self.activation == "swiglu" and recipe.delayed() and self.fused_swiglu:
+            return _FP8SwiGLUMLPFn.apply(ln, self.fc1_weight, self.fc1_bias, self.fc2_weight, self.fc2_bias,
+                                         _GemmSpec(recipe, mf, mb, 0, first, self.training))
         # fc1's backward is the last FP8 op of this module's backward -> it carries the update trigger
         h = _FP8LinearFn.apply(ln, self.fc1_bias, _GemmSpec(recipe, mf, mb, 0, first, self.training), self.fc1_weight)
         a = self.act_fn(h)

@@ -147,3 +147,72 @@ def gemm_mxfp8(a8, sa, b8, sb, fmt_a: int = E4M3, fmt_b: int = E4M3, bias=None, 
             rc = _lib.load().mi_gemm_mxfp8(*args)
     _lib.check(rc, "mi_gemm_mxfp8")
     return out
+
+
+def rope_qkv_forward(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n_q: int, n_kv: int, head_dim: int, seq: int):
+    """Split fused [T, (n_q + 2 n_kv) * D] bf16 into q [T, n_q*D], k, v [T, n_kv*D]; q, k rotated (row position = row % seq)."""
+    _dev(qkv, cos, sin)
+    assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous() and qkv.dim() == 2
+    T, W = qkv.shape
+    assert W == (n_q + 2 * n_kv) * head_dim and cos.dtype == torch.float32 and cos.shape[-1] == head_dim // 2 and cos.shape[0] >= seq
+    q = torch.empty((T, n_q * head_dim), dtype=torch.bfloat16, device=qkv.device)
+    k = torch.empty((T, n_kv * head_dim), dtype=torch.bfloat16, device=qkv.device)
+    v = torch.empty((T, n_kv * head_dim), dtype=torch.bfloat16, device=qkv.device)
+    rc = _lib.load().mi_rope_qkv(qkv.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                 T, seq, n_q, n_kv, head_dim, 0, _stream())
+    _lib.check(rc, "mi_rope_qkv")
+    return q, k, v
+
+
+def rope_qkv_backward(dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
+                      n_q: int, n_kv: int, head_dim: int, seq: int) -> torch.Tensor:
+    _dev(dq, dk, dv, cos, sin)
+    dq, dk, dv = (t.contiguous() for t in (dq, dk, dv))
+    T = dq.shape[0]
+    out = torch.empty((T, (n_q + 2 * n_kv) * head_dim), dtype=torch.bfloat16, device=dq.device)
+    rc = _lib.load().mi_rope_qkv(out.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                 T, seq, n_q, n_kv, head_dim, 1, _stream())
+    _lib.check(rc, "mi_rope_qkv")
+    return out
+
+
+def swiglu_cast(h: torch.Tensor, scale: torch.Tensor, amax: Optional[torch.Tensor], fmt: int, want_y: bool = True,
+                want_t: bool = True):
+    """K10 fwd.  h bf16 [R, 2F] -> (act8 [R, F], act8T [F, R]) with act = silu(gate) * up computed in fp32."""
+    _dev(h, scale, amax)
+    assert h.dtype == torch.bfloat16 and h.dim() == 2 and h.is_contiguous() and h.shape[1] % 2 == 0
+    R, F2 = h.shape
+    F = F2 // 2
+    y = torch.empty((R, F), dtype=torch.uint8, device=h.device) if want_y else None
+    yT = torch.empty((F, R), dtype=torch.uint8, device=h.device) if want_t else None
+    args = (h.data_ptr(), _ptr(y), _ptr(yT), scale.data_ptr(), _ptr(amax), R, F, fmt, _stream())
+    t = KernelTimer.active
+    if t is None:
+        rc = _lib.load().mi_swiglu_cast(*args)
+    else:
+        with t.span("swiglu_cast", f"{R}x{F}", float(R * F), float(R * F * (4 + int(want_y) + int(want_t)))):
+            rc = _lib.load().mi_swiglu_cast(*args)
+    _lib.check(rc, "mi_swiglu_cast")
+    return y, yT
+
+
+def dswiglu_cast(h: torch.Tensor, dact: torch.Tensor, scale: torch.Tensor, amax: Optional[torch.Tensor], fmt: int,
+                 want_y: bool = True, want_t: bool = True, want_colsum: bool = False):
+    """K10 bwd.  -> (dh8 [R, 2F], dh8T [2F, R], colsum fp32 [ceil(R/128), 2F] or None)."""
+    _dev(h, dact, scale, amax)
+    assert h.dtype == torch.bfloat16 and dact.dtype == torch.bfloat16 and h.is_contiguous() and dact.is_contiguous()
+    R, F2 = h.shape
+    F = F2 // 2
+    assert dact.shape == (R, F)
+    y = torch.empty((R, F2), dtype=torch.uint8, device=h.device) if want_y else None
+    yT = torch.empty((F2, R), dtype=torch.uint8, device=h.device) if want_t else None
+    cs = torch.empty(((R + 127) // 128, F2), dtype=torch.float32, device=h.device) if want_colsum else None
+    args = (h.data_ptr(), dact.data_ptr(), _ptr(y), _ptr(yT), scale.data_ptr(), _ptr(amax), _ptr(cs), R, F, fmt, _stream())
+    t = KernelTimer.active
+    if t is None:
+        rc = _lib.load().mi_dswiglu_cast(*args)
+    else:
+        with t.span("dswiglu_cast", f"{R}x{F}", float(R * F2), float(R * F * (6 + 2 * int(want_y) + 2 * int(want_t)))):
+            rc = _lib.load().mi_dswiglu_cast(*args)
+    _lib.check(rc, "mi_dswiglu_cast")
+    return y, yT, cs

@@ -342,3 +342,40 @@ def mxfp8_linear_fwd_bwd(x_bits, w_bits, dy_bits, bias_bits=None, fmt=E4M3):
     dw = gemm_mxfp8_tn(gt8, gte, xt8, xte, fmt, fmt)
     db = f32_to_bf16_bits(bf16_bits_to_f32(dy_bits).astype(np.float64).sum(axis=0).astype(np.float32))
     return y, dx, dw, db
+
+
+# --------------------------------------------------------------------------- fused elementwise neighbours (K10, RoPE)
+def swiglu_f32(h_bits: np.ndarray) -> np.ndarray:
+    """act = silu(gate) * up in float32 from bf16 h = [gate | up] (te_llama.py:62, SURVEY App. A "SwiGLU")."""
+    h = bf16_bits_to_f32(h_bits).astype(np.float64)
+    f = h.shape[1] // 2
+    g, u = h[:, :f], h[:, f:]
+    with np.errstate(over="ignore"):
+        return (g / (1.0 + np.exp(-g)) * u).astype(np.float32)
+
+
+def dswiglu_f32(h_bits: np.ndarray, dact_bits: np.ndarray) -> np.ndarray:
+    """dh = [dact * dsilu(g) * u | dact * silu(g)] in float32."""
+    h = bf16_bits_to_f32(h_bits).astype(np.float64)
+    d = bf16_bits_to_f32(dact_bits).astype(np.float64)
+    f = h.shape[1] // 2
+    g, u = h[:, :f], h[:, f:]
+    with np.errstate(over="ignore"):
+        s = 1.0 / (1.0 + np.exp(-g))
+    return np.concatenate([d * u * (s * (1.0 + g * (1.0 - s))), d * (g * s)], axis=1).astype(np.float32)
+
+
+def rope_f32(x_bits: np.ndarray, pos: np.ndarray, head_dim: int, base: float = 10000.0, conj: bool = False) -> np.ndarray:
+    """TE-style non-interleaved RoPE on [T, heads*D] (row t at position pos[t]); float32 math, one bf16 rounding."""
+    x = bf16_bits_to_f32(x_bits).astype(np.float64)
+    t, w = x.shape
+    half = head_dim // 2
+    inv = 1.0 / (base ** (np.arange(0, head_dim, 2, dtype=np.float32) / np.float32(head_dim))).astype(np.float32)
+    ang = (pos.astype(np.float32)[:, None] * inv[None, :]).astype(np.float32)
+    c, s = np.cos(ang.astype(np.float32)).astype(np.float64), np.sin(ang.astype(np.float32)).astype(np.float64)
+    if conj:
+        s = -s
+    xh = x.reshape(t, w // head_dim, head_dim)
+    x1, x2 = xh[..., :half], xh[..., half:]
+    out = np.concatenate([x1 * c[:, None, :] - x2 * s[:, None, :], x2 * c[:, None, :] + x1 * s[:, None, :]], axis=-1)
+    return f32_to_bf16_bits(out.reshape(t, w).astype(np.float32))

@@ -287,3 +287,79 @@ def test_gemm_mxfp8_vs_oracle(ops, dev, shape):
     assert (diff <= 7 * 2.0 ** -14 * mag + 1e-5 * np.abs(ref)).all()
     dbf = ops.gemm_mxfp8(t(a8), t(ae), t(b8), t(be))
     assert_gemm_close(dbf.float().cpu().numpy(), ref, f"mx gemm {shape}")
+
+
+# ----------------------------------------------------------------------------------------- fused neighbours (RoPE, K10)
+def _ulp_close_fp8(got, want, fmt, frac_exact=0.995):
+    """fp8 bytes equal, except where the fp32 value sits on a rounding boundary (device exp vs numpy exp): those may
+    differ by one code; at least `frac_exact` of the bytes must be identical."""
+    got, want = got.astype(np.int16), want.astype(np.int16)
+    diff = np.abs((got & 0x7F) - (want & 0x7F))
+    same_sign = ((got ^ want) & 0x80) == 0
+    ok = (diff == 0) & same_sign | (diff == 1) & same_sign | ((got & 0x7F) + (want & 0x7F) <= 1)
+    assert ok.all(), f"{(~ok).sum()} bytes differ by more than one fp8 code"
+    assert (diff == 0).mean() >= frac_exact, f"only {(diff == 0).mean():.4f} exact"
+
+
+@pytest.mark.parametrize("shape", [(8, 8), (136, 72), (1024, 3072)])
+@pytest.mark.parametrize("fmt", [O.E4M3, O.E5M2])
+def test_swiglu_cast_vs_oracle(ops, dev, shape, fmt):
+    R, F = shape
+    g = torch.Generator().manual_seed(R + F)
+    h = (torch.randn(R, 2 * F, generator=g) * 2).to(torch.bfloat16)
+    scale = np.float32(16.0)
+    amax = torch.zeros(1, dtype=torch.float32, device=dev)
+    y, yT = ops.swiglu_cast(h.to(dev), _f32(scale, dev), amax, fmt)
+    act = O.swiglu_f32(bf16_bits(h))
+    want = O.fp8_encode_sat((act * scale).astype(np.float32), fmt)
+    _ulp_close_fp8(u8(y), want, fmt)
+    np.testing.assert_array_equal(u8(yT), u8(y).T)
+    np.testing.assert_allclose(amax.item(), np.abs(act).max(), rtol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(8, 8), (136, 72), (1024, 3072)])
+def test_dswiglu_cast_vs_oracle(ops, dev, shape):
+    R, F = shape
+    g = torch.Generator().manual_seed(R * 3 + F)
+    h = (torch.randn(R, 2 * F, generator=g) * 2).to(torch.bfloat16)
+    d = (torch.randn(R, F, generator=g) / 8).to(torch.bfloat16)
+    scale = np.float32(64.0)
+    amax = torch.zeros(1, dtype=torch.float32, device=dev)
+    y, yT, cs = ops.dswiglu_cast(h.to(dev), d.to(dev), _f32(scale, dev), amax, O.E5M2, want_colsum=True)
+    dh = O.dswiglu_f32(bf16_bits(h), bf16_bits(d))
+    want = O.fp8_encode_sat((dh * scale).astype(np.float32), O.E5M2)
+    _ulp_close_fp8(u8(y), want, O.E5M2)
+    np.testing.assert_array_equal(u8(yT), u8(y).T)
+    np.testing.assert_allclose(amax.item(), np.abs(dh).max(), rtol=1e-5)
+    np.testing.assert_allclose(cs.sum(0).cpu().numpy(), dh.astype(np.float64).sum(0), rtol=1e-4, atol=1e-4 * np.abs(dh).max() * np.sqrt(R))
+    # the bias-gradient partial sums are bitwise reproducible
+    _, _, cs2 = ops.dswiglu_cast(h.to(dev), d.to(dev), _f32(scale, dev), None, O.E5M2, want_colsum=True)
+    assert torch.equal(cs, cs2)
+
+
+@pytest.mark.parametrize("B,S,nq,nkv,D", [(2, 16, 4, 2, 64), (1, 128, 24, 8, 128), (3, 40, 8, 8, 32)])
+def test_rope_qkv_split_and_merge_vs_oracle(ops, dev, B, S, nq, nkv, D):
+    import llm_fp8_amd.pytorch as te
+    g = torch.Generator().manual_seed(S)
+    W = (nq + 2 * nkv) * D
+    qkv = torch.randn(B * S, W, generator=g).to(torch.bfloat16)
+    freqs = te.attention.RotaryPositionEmbedding(D)(max_seq_len=256).to(dev)
+    from llm_fp8_amd.pytorch.attention import _cos_sin_tables
+    cos, sin = _cos_sin_tables(freqs, S)
+    q, k, v = ops.rope_qkv_forward(qkv.to(dev), cos, sin, nq, nkv, D, S)
+    pos = np.tile(np.arange(S), B)
+    bits = bf16_bits(qkv)
+    q_ref = O.rope_f32(bits[:, :nq * D], pos, D)
+    k_ref = O.rope_f32(bits[:, nq * D:(nq + nkv) * D], pos, D)
+    # device cos/sin come from torch.cos on the GPU: allow 1 bf16 ulp on a handful of elements
+    for got, ref in ((q, q_ref), (k, k_ref)):
+        gf, rf = got.float().cpu().numpy(), O.bf16_bits_to_f32(ref)
+        assert np.all(np.abs(gf - rf) <= 2.0 ** -7 * np.abs(rf) + 1e-5 * np.abs(qkv.float().numpy()).max())
+        assert (bf16_bits(got) == ref).mean() > 0.98
+    np.testing.assert_array_equal(bf16_bits(v), bits[:, (nq + nkv) * D:])
+    # backward = conjugate rotation merged back into the fused layout; rotation is orthogonal: merge(split(x)) ~ x
+    back = ops.rope_qkv_backward(q, k, v, cos, sin, nq, nkv, D, S)
+    bf, xf = back.float().cpu().numpy(), qkv.float().numpy()
+    assert np.all(np.abs(bf - xf) <= 2.0 ** -6 * np.abs(xf) + 2.0 ** -7 * np.abs(xf).max())
+    dq_ref = O.rope_f32(bf16_bits(q), pos, D, conj=True)
+    assert np.all(np.abs(back[:, :nq * D].float().cpu().numpy() - O.bf16_bits_to_f32(dq_ref)) <= 2.0 ** -7 * np.abs(O.bf16_bits_to_f32(dq_ref)) + 1e-5 * np.abs(xf).max())

@@ -283,3 +283,37 @@ def test_train_steps_run_and_update_once_per_step(te, dev, use_te, scenario):
     with torch.no_grad():
         out = model(**batch)
     assert torch.isfinite(out.loss)
+
+
+def test_fused_swiglu_mlp_matches_unfused(te, dev):
+    """K10 fusion (SwiGLU + cast in one kernel, bf16 activation never materialised) vs the two-Linear path:
+    same scales and amaxes up to the bf16 rounding of the activation the unfused path inserts."""
+    DelayedScaling, Format, _ = _recipes()
+    recipe = DelayedScaling(fp8_format=Format.HYBRID, amax_history_len=4, amax_compute_algo="max")
+    h, f = 256, 512
+    torch.manual_seed(11)
+    a = te.LayerNormMLP(h, f, normalization="RMSNorm", activation="swiglu", params_dtype=torch.bfloat16, device=dev)
+    b = te.LayerNormMLP(h, f, normalization="RMSNorm", activation="swiglu", params_dtype=torch.bfloat16, device=dev)
+    with torch.no_grad():
+        a.fc1_bias.normal_(0, 0.1); a.fc2_bias.normal_(0, 0.1)
+    b.load_state_dict(a.state_dict())
+    b.fused_swiglu = False
+    x = torch.randn(4, 64, h, device=dev, dtype=torch.bfloat16)
+    for step in range(3):
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        with te.fp8_autocast(enabled=True, fp8_recipe=recipe):
+            ya = a(xa)
+        with te.fp8_autocast(enabled=True, fp8_recipe=recipe):
+            yb = b(xb)
+        gy = torch.randn_like(ya) / 16
+        ya.backward(gy); yb.backward(gy)
+        for got, ref, name in ((ya, yb, "y"), (xa.grad, xb.grad, "dx"), (a.fc1_weight.grad, b.fc1_weight.grad, "dw1"),
+                               (a.fc2_weight.grad, b.fc2_weight.grad, "dw2"), (a.fc1_bias.grad, b.fc1_bias.grad, "db1"),
+                               (a.fc2_bias.grad, b.fc2_bias.grad, "db2")):
+            rel = (got.float() - ref.float()).norm() / ref.float().norm()
+            assert rel < 0.03, f"step {step} {name}: rel {rel:.4f}"
+        for p in list(a.parameters()) + list(b.parameters()):
+            p.grad = None
+    sa, sb = a._meta_fwd.state()["scale"], b._meta_fwd.state()["scale"]
+    assert torch.equal(sa[:2], sb[:2])  # fc1 input / weight amaxes are identical
+    assert torch.allclose(sa[3:5], sb[3:5], rtol=0.02)  # fc2 input amax: fp32 act vs bf16-rounded act
