@@ -93,9 +93,9 @@ int mi_gemm_fp8(const void* A, const void* B, void* D, const float* sa_inv, cons
  * K7  MXFP8 block quantise  [replaces TE's MXFP8 quantize, row-wise and column-wise].
  *   Row-wise: one E8M0 scale per 32 consecutive elements of a row:
  *     e = roundup_e8m0(amax_blk * (1/fp8_max)); y = sat_cast(x * 2^(127-e))
- *     y_row [rows, cols] fp8, s_row [rows, cols/32] u8.
+ *     y_row [rows, cols] fp8, s_row [cols/32, rows] u8 (BLOCK-MAJOR: the scales of one 32-block of every row are contiguous).
  *   Column-wise (blocks of 32 along rows), emitted TRANSPOSED so it is a TN GEMM operand:
- *     y_colT [cols, rows] fp8, s_colT [cols, rows/32] u8.
+ *     y_colT [cols, rows] fp8, s_colT [rows/32, cols] u8 (block-major w.r.t. the transposed operand).
  * Either pair may be NULL.  rows, cols multiples of 32.
  */
 int mi_mxfp8_quantize(const void* x_bf16, void* y_row, void* s_row, void* y_colT, void* s_colT,
@@ -104,7 +104,8 @@ int mi_mxfp8_quantize(const void* x_bf16, void* y_row, void* s_row, void* y_colT
 /*
  * K8  block-scaled MXFP8 GEMM (v_mfma_scale_f32_16x16x128_f8f6f4 with per-32 E8M0 scales)
  *   D[m,n] = bf16( sum_blk 2^(sa[m,blk]+sb[n,blk]-254) * sum_{k in blk} A[m,k] B[n,k] + bias[n] )
- * A [M,K] fp8 + SA [M,K/32] u8; B [N,K] fp8 + SB [N,K/32] u8; K multiple of 128.
+ * A [M,K] fp8 + SA [K/32, M] u8; B [N,K] fp8 + SB [K/32, N] u8 (block-major, as mi_mxfp8_quantize emits); K multiple of 32.
+ * algo: 0 = auto (persistent 256x256 kernel when M,N,K % 256 == 0, bf16 output, no bias; else generic), 1 = generic.
  */
 int mi_gemm_mxfp8(const void* A, const void* SA, const void* B, const void* SB, void* D,
                   const void* bias_bf16, int64_t M, int64_t N, int64_t K, int fmt_a, int fmt_b,

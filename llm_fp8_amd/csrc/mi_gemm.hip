@@ -109,8 +109,8 @@ __global__ __launch_bounds__(256) void gemm_generic(const uint8_t* __restrict__ 
       if (MX) {
         int blk = k0 / 32 + fq;
         // out-of-range rows / k-blocks multiply zero data: any finite scale works, use 2^0
-        sa[t] = (m0 + ra < M && blk < kb) ? (int)SA[(int64_t)(m0 + ra) * kb + blk] : 0x7F;
-        sb[t] = (n0 + rb < N && blk < kb) ? (int)SB[(int64_t)(n0 + rb) * kb + blk] : 0x7F;
+        sa[t] = (m0 + ra < M && blk < kb) ? (int)SA[(int64_t)blk * M + m0 + ra] : 0x7F;  // block-major [K/32, M]
+        sb[t] = (n0 + rb < N && blk < kb) ? (int)SB[(int64_t)blk * N + n0 + rb] : 0x7F;
       }
     }
 #pragma unroll
@@ -462,13 +462,15 @@ __device__ __forceinline__ void stage2(rsrc_t rs, const int (&voff)[2], int soff
 
 // Requires K % 256 == 0 (an even number of K-tiles, so every tile starts on LDS buffer 0) and
 // operand / output footprints < 2^31 bytes (32-bit buffer offsets); the host dispatcher checks both.
-template <int FA, int FB, int ABL = 0>
+template <int FA, int FB, int ABL = 0, bool MX = false>
 __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
                                                       uint16_t* __restrict__ D, const float* __restrict__ sa_inv,
                                                       const float* __restrict__ sb_inv, int K, int lda, int ldb,
                                                       int ldd, int tiles_m, int tiles_n, int a_bytes, int b_bytes,
-                                                      int d_bytes) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes];
+                                                      int d_bytes, const uint8_t* __restrict__ SA,
+                                                      const uint8_t* __restrict__ SB, int M, int N) {
+  // MX: + 2 slots x {A, B} x 4 k-blocks x 256 rows of E8M0 scales behind the operand buffers
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes + (MX ? 4096 : 0)];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -477,10 +479,22 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   const int bid = blockIdx.x;
   const int my_tiles = (ntiles - bid + G - 1) / G;  // tiles bid, bid + G, ...
   const int nk = K / BK;
-  const float alpha = (*sa_inv) * (*sb_inv);
+  const float alpha = MX ? 1.0f : (*sa_inv) * (*sb_inv);
   const rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
   const rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
   const rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)D, 0, d_bytes, 0x00020000);
+  // MX scales are block-major [K/32, rows]; wave w stages the 256 scale bytes of (operand w>>2, k-block w&3)
+  const bool s_is_b = wave >= 4;
+  const int s_rows = s_is_b ? N : M;
+  const rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(MX ? (s_is_b ? SB : SA) : A), 0, MX ? (K / 32) * s_rows : 0, 0x00020000);
+  uint8_t* const sbuf = lds + kLdsBytes;  // [slot][operand][4][256]
+  auto stage_scales = [&](int slot, int kt, int row0a, int row0b) {
+    if (MX) {
+      const int soff = (kt * 4 + (wave & 3)) * s_rows + (s_is_b ? row0b : row0a);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, LDS_PTR(sbuf + slot * 2048 + (wave >> 2) * 1024 + (wave & 3) * 256), 4,
+                                               lane * 4, soff, 0, 0);
+    }
+  };
   v4f acc[2][4][2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -507,33 +521,39 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
 
   // pipeline cursors (wave-uniform byte offsets of the (tile, K-tile) of step s+1 / s+2, clamped to the last step)
   const int total = my_tiles * nk;
-  auto tile_origin = [&](int ti, int& oa, int& ob) {
+  int ra_1 = 0, rb_1 = 0;  // row origins (tm*256, tn*256) of cursor 1's tile, for the MX scale stage
+  auto tile_origin = [&](int ti, int& oa, int& ob, int& ra, int& rb) {
     int tm, tn;
     tile_of_block(bid + ti * G, ntiles, tiles_m, tiles_n, tm, tn);
     oa = tm * BM * lda;
     ob = tn * BN * ldb;
+    ra = tm * BM;
+    rb = tn * BN;
   };
   int oa_1, ob_1, oa_2, ob_2, ti_1 = 0, kt_1 = 0, ti_2 = 0, kt_2 = 0;
-  int oa_0, ob_0;
-  tile_origin(0, oa_0, ob_0);
+  int oa_0, ob_0, ra_0, rb_0, ra_2, rb_2;
+  tile_origin(0, oa_0, ob_0, ra_0, rb_0);
   oa_1 = oa_2 = oa_0;
   ob_1 = ob_2 = ob_0;
-  auto advance = [&](int& ti, int& kt, int& oa, int& ob, int step) {
+  ra_1 = ra_2 = ra_0;
+  rb_1 = rb_2 = rb_0;
+  auto advance = [&](int& ti, int& kt, int& oa, int& ob, int& ra, int& rb, int step) {
     if (step < total) {
       if (++kt == nk) {
         kt = 0;
         ++ti;
-        tile_origin(ti, oa, ob);
+        tile_origin(ti, oa, ob, ra, rb);
       }
     }
   };
-  advance(ti_1, kt_1, oa_1, ob_1, 1);
-  ti_2 = ti_1; kt_2 = kt_1; oa_2 = oa_1; ob_2 = ob_1;
-  advance(ti_2, kt_2, oa_2, ob_2, 2);
+  advance(ti_1, kt_1, oa_1, ob_1, ra_1, rb_1, 1);
+  ti_2 = ti_1; kt_2 = kt_1; oa_2 = oa_1; ob_2 = ob_1; ra_2 = ra_1; rb_2 = rb_1;
+  advance(ti_2, kt_2, oa_2, ob_2, ra_2, rb_2, 2);
 
   uint8_t* const buf0 = lds;
   uint8_t* const buf1 = lds + kBufBytes;
   // prologue: step 0 complete, (step 1: A0, B0) in flight
+  stage_scales(0, 0, ra_0, rb_0);
   stage2(rsA, a_voff, oa_0, buf0 + kOffA0, wave);
   stage2(rsB, b_voff, ob_0, buf0 + kOffB0, wave);
   stage2(rsB, b_voff, ob_0 + b_h1, buf0 + kOffB1, wave);
@@ -546,12 +566,20 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   if (wr == 1) __builtin_amdgcn_s_barrier();
 
   v8i af[4], b0f[2], b1f[2];
+  int as_[4] = {kUnitScale, kUnitScale, kUnitScale, kUnitScale}, b0s[2] = {kUnitScale, kUnitScale}, b1s[2] = {kUnitScale, kUnitScale};
+  const int sfr = lane & 15, sfq = lane >> 4;
   int s = 0;  // current step
   // one K-tile = 4 phases.  `after_epi` (uniform): this is the first K-tile behind an epilogue, so the 16 stores
   // sit between the awaited loads and the younger ones -> wait with vmcnt(8 + 16).
-#define MI_WAIT_SYNC(after_epi)                                        \
-  if (after_epi) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");     \
-  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                \
+  // MX issues one more LDS-DMA per K-tile (the scale piece, first op of phase 0), so phases 0-2 wait with 9 / 25.
+#define MI_WAIT_SYNC(after_epi, P3)                                                                    \
+  if (MX && !(P3)) {                                                                                   \
+    if (after_epi) asm volatile("s_waitcnt vmcnt(25)" ::: "memory");                                   \
+    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                                              \
+  } else {                                                                                             \
+    if (after_epi) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                                   \
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                              \
+  }                                                                                                    \
   __builtin_amdgcn_s_barrier();                                        \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   \
   __builtin_amdgcn_sched_barrier(0);                                   \
@@ -559,7 +587,8 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
 #define MI_PIN8(EXPR)                                                  \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                        \
   _Pragma("unroll") for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(EXPR));
-  auto ktile = [&](uint8_t* cur, uint8_t* oth, bool after_epi) {
+  auto ktile = [&](uint8_t* cur, uint8_t* oth, bool after_epi, int slot) {
+    const uint8_t* sc = sbuf + slot * 2048 + sfq * 256 + sfr;  // + operand*1024 + tile row of the fragment
     const int sa1 = oa_1 + kt_1 * BK, sb1 = ob_1 + kt_1 * BK;
     const int sa2 = oa_2 + kt_2 * BK, sb2 = ob_2 + kt_2 * BK;
     // ---- phase 0
@@ -567,49 +596,64 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
     for (int j = 0; j < 2; ++j) b0f[j] = read_frag(cur + kOffB0, wc * 2 + j, lane);
 #pragma unroll
     for (int i = 0; i < 4; ++i) af[i] = read_frag(cur + kOffA0, wr * 4 + i, lane);
+    if (MX) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b0s[j] = sc[1024 + wc * 64 + j * 16];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) as_[i] = sc[wr * 128 + i * 16];
+    }
+    stage_scales(slot ^ 1, kt_1, ra_1, rb_1);
     stage2(rsB, b_voff, sb1 + b_h1, oth + kOffB1, wave);
-    MI_WAIT_SYNC(after_epi)
+    MI_WAIT_SYNC(after_epi, false)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[0][i][0][j] = mfma_ba<FA, FB>(af[i], b0f[j], acc[0][i][0][j], kUnitScale, kUnitScale);
+      for (int j = 0; j < 2; ++j) acc[0][i][0][j] = mfma_ba<FA, FB>(af[i], b0f[j], acc[0][i][0][j], as_[i], b0s[j]);
     MI_PIN8(acc[0][i][0][j])
     MI_PHASE_END();
     // ---- phase 1
 #pragma unroll
     for (int j = 0; j < 2; ++j) b1f[j] = read_frag(cur + kOffB1, wc * 2 + j, lane);
+    if (MX) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b1s[j] = sc[1024 + wc * 64 + 32 + j * 16];
+    }
     stage2(rsA, a_voff, sa1 + a_h1, oth + kOffA1, wave);
-    MI_WAIT_SYNC(after_epi)
+    MI_WAIT_SYNC(after_epi, false)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[0][i][1][j] = mfma_ba<FA, FB>(af[i], b1f[j], acc[0][i][1][j], kUnitScale, kUnitScale);
+      for (int j = 0; j < 2; ++j) acc[0][i][1][j] = mfma_ba<FA, FB>(af[i], b1f[j], acc[0][i][1][j], as_[i], b1s[j]);
     MI_PIN8(acc[0][i][1][j])
     MI_PHASE_END();
     // ---- phase 2
 #pragma unroll
     for (int i = 0; i < 4; ++i) af[i] = read_frag(cur + kOffA1, wr * 4 + i, lane);
+    if (MX) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) as_[i] = sc[wr * 128 + 64 + i * 16];
+    }
     stage2(rsA, a_voff, sa2, cur + kOffA0, wave);
-    MI_WAIT_SYNC(after_epi)
+    MI_WAIT_SYNC(after_epi, false)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[1][i][1][j] = mfma_ba<FA, FB>(af[i], b1f[j], acc[1][i][1][j], kUnitScale, kUnitScale);
+      for (int j = 0; j < 2; ++j) acc[1][i][1][j] = mfma_ba<FA, FB>(af[i], b1f[j], acc[1][i][1][j], as_[i], b1s[j]);
     MI_PIN8(acc[1][i][1][j])
     MI_PHASE_END();
     // ---- phase 3
     stage2(rsB, b_voff, sb2, cur + kOffB0, wave);
-    MI_WAIT_SYNC(after_epi)
+    MI_WAIT_SYNC(after_epi, true)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[1][i][0][j] = mfma_ba<FA, FB>(af[i], b0f[j], acc[1][i][0][j], kUnitScale, kUnitScale);
+      for (int j = 0; j < 2; ++j) acc[1][i][0][j] = mfma_ba<FA, FB>(af[i], b0f[j], acc[1][i][0][j], as_[i], b0s[j]);
     MI_PIN8(acc[1][i][0][j])
     MI_PHASE_END();
     // cursors follow the step
     ++s;
-    advance(ti_1, kt_1, oa_1, ob_1, s + 1);
-    advance(ti_2, kt_2, oa_2, ob_2, s + 2);
+    advance(ti_1, kt_1, oa_1, ob_1, ra_1, rb_1, s + 1);
+    advance(ti_2, kt_2, oa_2, ob_2, ra_2, rb_2, s + 2);
   };
 
   const int fr = lane & 15, fq = lane >> 4;
@@ -647,8 +691,8 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
 
   int kt = 0, ti = 0;
   for (int pair = 0; pair < total / 2; ++pair) {
-    ktile(buf0, buf1, kt == 0 && ti > 0);
-    ktile(buf1, buf0, false);
+    ktile(buf0, buf1, kt == 0 && ti > 0, 0);
+    ktile(buf1, buf0, false, 1);
     kt += 2;
     if (kt == nk) {
       epilogue(ti);
@@ -692,10 +736,18 @@ static int launch_fmt(const void* A, const void* B, void* D, const float* sa_inv
     int grid = tiles_m * tiles_n < num_cus() ? tiles_m * tiles_n : num_cus();
     if (algo == 4)
       hipLaunchKernelGGL((gemm_256_p8<FA, FB, 0>), dim3(grid), dim3(512), 0, st, a, b, (uint16_t*)D, sa_inv, sb_inv, (int)K,
-                         (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb), (int)(M * ldd * 2));
+                         (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb), (int)(M * ldd * 2),
+                         nullptr, nullptr, (int)M, (int)N);
     else
       hipLaunchKernelGGL((gemm_256_p8<FA, FB, 1>), dim3(grid), dim3(512), 0, st, a, b, (uint16_t*)D, sa_inv, sb_inv, (int)K,
-                         (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb), (int)(M * ldd * 2));
+                         (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb), (int)(M * ldd * 2),
+                         nullptr, nullptr, (int)M, (int)N);
+  } else if (algo == 4 && mx) {
+    int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
+    int grid = tiles_m * tiles_n < num_cus() ? tiles_m * tiles_n : num_cus();
+    hipLaunchKernelGGL((gemm_256_p8<FA, FB, 0, true>), dim3(grid), dim3(512), 0, st, a, b, (uint16_t*)D, sa_inv, sb_inv, (int)K,
+                       (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb), (int)(M * ldd * 2),
+                       (const uint8_t*)SA, (const uint8_t*)SB, (int)M, (int)N);
   } else if (algo == 13 && !mx) {
     int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
     hipLaunchKernelGGL((gemm_256_8ph<FA, FB, OUT, 1>), dim3(tiles_m * tiles_n), dim3(512), 0, st, a, b, D, sa_inv, sb_inv,
@@ -793,8 +845,16 @@ extern "C" int mi_gemm_mxfp8(const void* A, const void* SA, const void* B, const
   if (rc != MI_OK) return rc;
   MI_CHECK_ARG(SA && SB, "mi_gemm_mxfp8: null scale pointer");
   MI_CHECK_ARG(K % 32 == 0, "mi_gemm_mxfp8: K must be a multiple of 32");
+  MI_CHECK_ARG(algo == 0 || algo == 1 || algo == 4, "mi_gemm_mxfp8: algo must be 0, 1 or 4");
   if (M == 0 || N == 0) return MI_OK;
-  (void)algo;
-  return mi::dispatch(A, B, D, nullptr, nullptr, SA, SB, bias_bf16, M, N, K, K, K, N, fmt_a, fmt_b, out_dtype, 1, true,
+  int a = algo == 0 ? 4 : algo;
+  if (a == 4) {
+    a = mi::pick_algo(4, M, N, K, K, K, N, out_dtype, bias_bf16 != nullptr, "mi_gemm_mxfp8");
+    if (a < 0) {
+      if (algo == 4) return a;
+      a = 1;  // auto: fall back to the generic kernel
+    }
+  }
+  return mi::dispatch(A, B, D, nullptr, nullptr, SA, SB, bias_bf16, M, N, K, K, K, N, fmt_a, fmt_b, out_dtype, a, true,
                       (hipStream_t)stream);
 }

@@ -2,6 +2,9 @@
 // GEMM contraction axis.  Both orientations in ONE pass over the bf16 input (2 B read, 2 B + 2/32 B
 // written per element): the row-wise copy (blocks along the last dim) feeds fprop, the column-wise
 // copy (blocks along the first dim, emitted transposed) feeds dgrad / wgrad.
+// Scales are stored BLOCK-MAJOR ([K/32, rows]: all rows' scales of one 32-block are contiguous): the quantiser
+// writes 8 bytes per lane instead of 8 single bytes and the GEMM stages one K-tile's scales of a 256-row tile as
+// four 256-byte runs.
 // Same tiling as the delayed-scaling cast: 128x128 tile per workgroup, 8x8 block per lane; a
 // 32-element block spans 4 neighbouring lanes, reduced with two DPP shuffles.
 // Replaces TE's MXFP8 quantise under MXFP8BlockScaling(fp8_format=E4M3)
@@ -86,10 +89,10 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
       uint8_t* dst = y_row + (int64_t)r0 * cols + c0;
 #pragma unroll
       for (int i = 0; i < 8; ++i) *reinterpret_cast<uint2*>(dst + (int64_t)i * cols) = make_uint2(lo[i], hi[i]);
-      if ((lane & 3) == 0) {
-        const int kb = cols / 32;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) s_row[(int64_t)(r0 + i) * kb + c0 / 32] = (uint8_t)sbytes[i];
+      if ((lane & 3) == 0) {  // block-major scales [cols/32, rows]: this lane's 8 rows are 8 contiguous bytes
+        const u32 lo4 = sbytes[0] | (sbytes[1] << 8) | (sbytes[2] << 16) | (sbytes[3] << 24);
+        const u32 hi4 = sbytes[4] | (sbytes[5] << 8) | (sbytes[6] << 16) | (sbytes[7] << 24);
+        *reinterpret_cast<uint2*>(s_row + (int64_t)(c0 / 32) * rows + r0) = make_uint2(lo4, hi4);
       }
     }
   }
@@ -125,10 +128,10 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
         *reinterpret_cast<uint2*>(dst + (int64_t)j * rows) = make_uint2(a[j], b[j]);
         *reinterpret_cast<uint2*>(dst + (int64_t)(j + 4) * rows) = make_uint2(c[j], d[j]);
       }
-      if (((lane >> 3) & 3) == 0) {
-        const int rb = rows / 32;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s_colT[(int64_t)(c0 + j) * rb + r0 / 32] = (uint8_t)sbytes[j];
+      if (((lane >> 3) & 3) == 0) {  // block-major scales [rows/32, cols]: 8 contiguous bytes for this lane's 8 columns
+        const u32 lo4 = sbytes[0] | (sbytes[1] << 8) | (sbytes[2] << 16) | (sbytes[3] << 24);
+        const u32 hi4 = sbytes[4] | (sbytes[5] << 8) | (sbytes[6] << 16) | (sbytes[7] << 24);
+        *reinterpret_cast<uint2*>(s_colT + (int64_t)(r0 / 32) * cols + c0) = make_uint2(lo4, hi4);
       }
     }
   }

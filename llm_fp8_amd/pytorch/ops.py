@@ -103,17 +103,18 @@ def gemm_fp8(a8: torch.Tensor, b8: torch.Tensor, sa_inv: torch.Tensor, sb_inv: t
 
 
 def mxfp8_quantize(x: torch.Tensor, fmt: int = E4M3, rowwise: bool = True, colwise: bool = True):
-    """K7.  Returns (y_row [R,C], s_row [R,C/32], y_colT [C,R], s_colT [C,R/32]) (None where not asked)."""
+    """K7.  Returns (y_row [R,C], s_row [C/32,R], y_colT [C,R], s_colT [R/32,C]) (None where not asked); scales are
+    block-major: the E8M0 bytes of one 32-block of every row are contiguous."""
     _dev(x)
     assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.is_contiguous()
     R, C = x.shape
     y_row = s_row = y_colT = s_colT = None
     if rowwise:
         y_row = torch.empty((R, C), dtype=torch.uint8, device=x.device)
-        s_row = torch.empty((R, C // 32), dtype=torch.uint8, device=x.device)
+        s_row = torch.empty((C // 32, R), dtype=torch.uint8, device=x.device)
     if colwise:
         y_colT = torch.empty((C, R), dtype=torch.uint8, device=x.device)
-        s_colT = torch.empty((C, R // 32), dtype=torch.uint8, device=x.device)
+        s_colT = torch.empty((R // 32, C), dtype=torch.uint8, device=x.device)
     args = (x.data_ptr(), _ptr(y_row), _ptr(s_row), _ptr(y_colT), _ptr(s_colT), R, C, fmt, _stream())
     t = KernelTimer.active
     if t is None:
@@ -133,7 +134,7 @@ def gemm_mxfp8(a8, sa, b8, sb, fmt_a: int = E4M3, fmt_b: int = E4M3, bias=None, 
     M, K = a8.shape
     N, K2 = b8.shape
     assert K == K2 and a8.is_contiguous() and b8.is_contiguous() and sa.is_contiguous() and sb.is_contiguous()
-    assert sa.shape == (M, K // 32) and sb.shape == (N, K // 32)
+    assert sa.shape == (K // 32, M) and sb.shape == (K // 32, N), "scales must be block-major [K/32, rows]"
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=a8.device)
     assert out.is_contiguous() and out.shape == (M, N)

@@ -257,9 +257,9 @@ def test_mxfp8_quantize_bitexact(ops, dev, shape, fmt):
     y_row, s_row, y_colT, s_colT = ops.mxfp8_quantize(x.to(dev), fmt)
     q, e = O.mxfp8_quantize_rowwise(bits, fmt)
     qc, ec = O.mxfp8_quantize_colwise(bits, fmt)
-    np.testing.assert_array_equal(u8(s_row), e)
+    np.testing.assert_array_equal(u8(s_row), e.T)  # device scales are block-major [C/32, R]
     np.testing.assert_array_equal(u8(y_row), q)
-    np.testing.assert_array_equal(u8(s_colT), ec)
+    np.testing.assert_array_equal(u8(s_colT), ec.T)
     np.testing.assert_array_equal(u8(y_colT), qc)
     yr, sr, yc, sc = ops.mxfp8_quantize(x.to(dev), fmt, colwise=False)
     assert yc is None and sc is None
@@ -269,9 +269,13 @@ def test_mxfp8_quantize_bitexact(ops, dev, shape, fmt):
     np.testing.assert_array_equal(u8(yc), qc)
 
 
-@pytest.mark.parametrize("shape", [(32, 32, 32), (64, 96, 128), (96, 160, 320), (256, 512, 1024)])
-def test_gemm_mxfp8_vs_oracle(ops, dev, shape):
+@pytest.mark.parametrize("shape", [(32, 32, 32), (64, 96, 128), (96, 160, 320), (256, 512, 1024), (256, 256, 256),
+                                   (768, 512, 512), (2048, 2304, 768)])
+@pytest.mark.parametrize("algo", [1, 4])
+def test_gemm_mxfp8_vs_oracle(ops, dev, shape, algo):
     M, N, K = shape
+    if algo == 4 and (M % 256 or N % 256 or K % 256):
+        pytest.skip("persistent MX kernel needs 256-aligned shapes")
     g = torch.Generator().manual_seed(M + K)
     a = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, K // 32, generator=g).repeat_interleave(32, 1) * 2)).to(torch.bfloat16)
     b = (torch.randn(N, K, generator=g) * torch.exp(torch.randn(N, K // 32, generator=g).repeat_interleave(32, 1) * 2)).to(torch.bfloat16)
@@ -279,13 +283,14 @@ def test_gemm_mxfp8_vs_oracle(ops, dev, shape):
     b8, be = O.mxfp8_quantize_rowwise(bf16_bits(b))
     ref = O.gemm_mxfp8_tn(a8, ae, b8, be, out_f32=True)
     t = lambda v: torch.from_numpy(v).to(dev)
-    d = ops.gemm_mxfp8(t(a8), t(ae), t(b8), t(be), out_dtype=torch.float32)
+    tT = lambda v: torch.from_numpy(np.ascontiguousarray(v.T)).to(dev)  # block-major scales
+    d = ops.gemm_mxfp8(t(a8), tT(ae), t(b8), tT(be), out_dtype=torch.float32, algo=1)
     sa = np.repeat(O.e8m0_to_f32(ae).astype(np.float64), 32, axis=1)
     sb = np.repeat(O.e8m0_to_f32(be).astype(np.float64), 32, axis=1)
     mag = (np.abs(O.fp8_decode(a8, O.E4M3)) * sa) @ (np.abs(O.fp8_decode(b8, O.E4M3)) * sb).T
     diff = np.abs(d.cpu().numpy().astype(np.float64) - ref)
     assert (diff <= 7 * 2.0 ** -14 * mag + 1e-5 * np.abs(ref)).all()
-    dbf = ops.gemm_mxfp8(t(a8), t(ae), t(b8), t(be))
+    dbf = ops.gemm_mxfp8(t(a8), tT(ae), t(b8), tT(be), algo=algo)
     assert_gemm_close(dbf.float().cpu().numpy(), ref, f"mx gemm {shape}")
 
 

@@ -49,6 +49,16 @@ def main():
                     tf = 2.0 * m * n * k / t / 1e12
                     print(f"gemm {name:4s} {kind:5s} {m:6d}x{n:6d}x{k:6d} algo {algo}: {t*1e6:9.1f} us {tf:8.1f} TFLOP/s "
                           f"({tf/5000*100:5.1f}% of 5 PF)", flush=True)
+    if "mxgemm" in args.which:
+        for name, (M, N, K) in SHAPES_3B.items():
+            for kind, (m, n, k) in (("fprop", (M, N, K)), ("dgrad", (M, K, N)), ("wgrad", (N, K, M))):
+                a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
+                sa = torch.randint(120, 131, (k // 32, m), generator=g, device=dev, dtype=torch.uint8)
+                sb = torch.randint(120, 131, (k // 32, n), generator=g, device=dev, dtype=torch.uint8)
+                out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+                t = time_fn(lambda: ops.gemm_mxfp8(a, sa, b, sb, 0, 0, out=out, algo=4), args.iters)
+                tf = 2.0 * m * n * k / t / 1e12
+                print(f"mxgemm {name:4s} {kind:5s} {m:6d}x{n:6d}x{k:6d}: {t*1e6:9.1f} us {tf:8.1f} TFLOP/s ({tf/5000*100:5.1f}% of 5 PF)", flush=True)
     if "ksweep" in args.which:
         # fixed 8192x8192 output (1024 tiles = 4 full rounds), K sweep: slope = mainloop cost per K-tile, intercept = per-tile overhead
         for algo in [int(x) for x in args.algos.split(",")]:
