@@ -82,8 +82,8 @@ int mi_scale_update(float* amax_history, float* scale, float* scale_inv, const f
  * bias: bf16 [N] or NULL.  M, N multiples of 16 (8 for the generic path), K multiple of 16.
  * algo: 0 = auto, 1 = generic 64x64 tile, 2 = 256x256 two-phase, 3 = 256x256 eight-phase ping-pong,
  *       4 = persistent eight-phase (one workgroup per CU, epilogue overlapped with the next tile).
- * 2/3 need M,N % 256 == 0 and K % 128 == 0; 4 additionally K % 256 == 0, bf16 output, no bias and
- * operands below 2 GiB.  auto picks 4, else 3, else 1.  (13-15 are timing-only diagnostic builds.)
+ * 2/3 need M,N % 256 == 0 and K % 128 == 0; 4 additionally K % 256 == 0, bf16 output and operands
+ * below 2 GiB.  auto picks 4, else 3, else 1.  (13-15 are timing-only diagnostic builds.)
  */
 int mi_gemm_fp8(const void* A, const void* B, void* D, const float* sa_inv, const float* sb_inv,
                 const void* bias_bf16, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
@@ -105,7 +105,7 @@ int mi_mxfp8_quantize(const void* x_bf16, void* y_row, void* s_row, void* y_colT
  * K8  block-scaled MXFP8 GEMM (v_mfma_scale_f32_16x16x128_f8f6f4 with per-32 E8M0 scales)
  *   D[m,n] = bf16( sum_blk 2^(sa[m,blk]+sb[n,blk]-254) * sum_{k in blk} A[m,k] B[n,k] + bias[n] )
  * A [M,K] fp8 + SA [K/32, M] u8; B [N,K] fp8 + SB [K/32, N] u8 (block-major, as mi_mxfp8_quantize emits); K multiple of 32.
- * algo: 0 = auto (persistent 256x256 kernel when M,N,K % 256 == 0, bf16 output, no bias; else generic), 1 = generic.
+ * algo: 0 = auto (persistent 256x256 kernel when M,N,K % 256 == 0 and bf16 output; else generic), 1 = generic.
  */
 int mi_gemm_mxfp8(const void* A, const void* SA, const void* B, const void* SB, void* D,
                   const void* bias_bf16, int64_t M, int64_t N, int64_t K, int fmt_a, int fmt_b,

@@ -462,15 +462,18 @@ __device__ __forceinline__ void stage2(rsrc_t rs, const int (&voff)[2], int soff
 
 // Requires K % 256 == 0 (an even number of K-tiles, so every tile starts on LDS buffer 0) and
 // operand / output footprints < 2^31 bytes (32-bit buffer offsets); the host dispatcher checks both.
-template <int FA, int FB, int ABL = 0, bool MX = false>
+template <int FA, int FB, int ABL = 0, bool MX = false, bool BIAS = false>
 __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
                                                       uint16_t* __restrict__ D, const float* __restrict__ sa_inv,
                                                       const float* __restrict__ sb_inv, int K, int lda, int ldb,
                                                       int ldd, int tiles_m, int tiles_n, int a_bytes, int b_bytes,
                                                       int d_bytes, const uint8_t* __restrict__ SA,
-                                                      const uint8_t* __restrict__ SB, int M, int N) {
-  // MX: + 2 slots x {A, B} x 4 k-blocks x 256 rows of E8M0 scales behind the operand buffers
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes + (MX ? 4096 : 0)];
+                                                      const uint8_t* __restrict__ SB, int M, int N,
+                                                      const uint16_t* __restrict__ bias) {
+  // behind the operand buffers: 4 KiB of E8M0 scales (MX: 2 slots x {A, B} x 4 k-blocks x 256 rows) and 4 KiB of
+  // bias windows (BIAS: 2 slots x 8 waves x 256 B)
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes + ((MX || BIAS) ? 8192 : 0)];
+  constexpr int EX = (MX ? 1 : 0) + (BIAS ? 1 : 0);  // extra LDS-DMA ops per K-tile, issued at the head of phase 0
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -488,6 +491,15 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   const int s_rows = s_is_b ? N : M;
   const rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(MX ? (s_is_b ? SB : SA) : A), 0, MX ? (K / 32) * s_rows : 0, 0x00020000);
   uint8_t* const sbuf = lds + kLdsBytes;  // [slot][operand][4][256]
+  // bias: every K-tile each wave re-fetches the 256-byte window that starts at its own 64 columns of cursor 1's tile
+  // (one dword per lane; reads past N return 0 through the descriptor's range check) -> uniform vmcnt accounting
+  const rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)(BIAS ? (const void*)bias : (const void*)A), 0, BIAS ? N * 2 : 0, 0x00020000);
+  uint8_t* const bbuf = lds + kLdsBytes + 4096;  // [slot][wave][256 B]
+  auto stage_bias = [&](int slot, int col0) {
+    if (BIAS)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBias, LDS_PTR(bbuf + (slot * 8 + wave) * 256), 4, lane * 4,
+                                               (col0 + wc * 64) * 2, 0, 0);
+  };
   auto stage_scales = [&](int slot, int kt, int row0a, int row0b) {
     if (MX) {
       const int soff = (kt * 4 + (wave & 3)) * s_rows + (s_is_b ? row0b : row0a);
@@ -554,6 +566,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   uint8_t* const buf1 = lds + kBufBytes;
   // prologue: step 0 complete, (step 1: A0, B0) in flight
   stage_scales(0, 0, ra_0, rb_0);
+  stage_bias(0, rb_0);
   stage2(rsA, a_voff, oa_0, buf0 + kOffA0, wave);
   stage2(rsB, b_voff, ob_0, buf0 + kOffB0, wave);
   stage2(rsB, b_voff, ob_0 + b_h1, buf0 + kOffB1, wave);
@@ -571,9 +584,12 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   int s = 0;  // current step
   // one K-tile = 4 phases.  `after_epi` (uniform): this is the first K-tile behind an epilogue, so the 16 stores
   // sit between the awaited loads and the younger ones -> wait with vmcnt(8 + 16).
-  // MX issues one more LDS-DMA per K-tile (the scale piece, first op of phase 0), so phases 0-2 wait with 9 / 25.
+  // MX / BIAS each issue one more LDS-DMA per K-tile (first ops of phase 0), so phases 0-2 wait with 8 + EX (+16).
 #define MI_WAIT_SYNC(after_epi, P3)                                                                    \
-  if (MX && !(P3)) {                                                                                   \
+  if (EX == 2 && !(P3)) {                                                                              \
+    if (after_epi) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");                                   \
+    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                             \
+  } else if (EX == 1 && !(P3)) {                                                                       \
     if (after_epi) asm volatile("s_waitcnt vmcnt(25)" ::: "memory");                                   \
     else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                                              \
   } else {                                                                                             \
@@ -603,6 +619,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
       for (int i = 0; i < 4; ++i) as_[i] = sc[wr * 128 + i * 16];
     }
     stage_scales(slot ^ 1, kt_1, ra_1, rb_1);
+    stage_bias(ti_1 & 1, rb_1);
     stage2(rsB, b_voff, sb1 + b_h1, oth + kOffB1, wave);
     MI_WAIT_SYNC(after_epi, false)
 #pragma unroll
@@ -663,6 +680,20 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
     int tm, tn;
     tile_of_block(bid + ti * G, ntiles, tiles_m, tiles_n, tm, tn);
     const int d_tile = (tm * BM * ldd + tn * BN) * 2;  // uniform, bytes
+    float bv[2][2][4];
+    if (BIAS) {  // this wave's own LDS-DMA data: covered by the vmcnt waits of the last K-tile, no barrier needed
+      const uint8_t* bp = bbuf + ((ti & 1) * 8 + wave) * 256 + fq * 8;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const uint2 w = *reinterpret_cast<const uint2*>(bp + (b * 32 + j * 16) * 2);
+          bv[b][j][0] = __uint_as_float(w.x << 16);
+          bv[b][j][1] = __uint_as_float(w.x & 0xFFFF0000u);
+          bv[b][j][2] = __uint_as_float(w.y << 16);
+          bv[b][j][3] = __uint_as_float(w.y & 0xFFFF0000u);
+        }
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -670,6 +701,13 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           v4f v0 = acc[a][i][b][0] * alpha, v1 = acc[a][i][b][1] * alpha;
+          if (BIAS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v0[e] += bv[b][0][e];
+              v1[e] += bv[b][1][e];
+            }
+          }
           u32 p0x = pack_bf16x2(v0[0], v0[1]), p0y = pack_bf16x2(v0[2], v0[3]);
           u32 p1x = pack_bf16x2(v1[0], v1[1]), p1y = pack_bf16x2(v1[2], v1[3]);
           auto sx = __builtin_amdgcn_permlane16_swap(p0x, p1x, false, false);
@@ -734,20 +772,29 @@ static int launch_fmt(const void* A, const void* B, void* D, const float* sa_inv
   } else if ((algo == 4 || algo == 15) && !mx) {
     int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
     int grid = tiles_m * tiles_n < num_cus() ? tiles_m * tiles_n : num_cus();
-    if (algo == 4)
+    if (algo == 4 && bp)
+      hipLaunchKernelGGL((gemm_256_p8<FA, FB, 0, false, true>), dim3(grid), dim3(512), 0, st, a, b, (uint16_t*)D, sa_inv, sb_inv,
+                         (int)K, (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb),
+                         (int)(M * ldd * 2), nullptr, nullptr, (int)M, (int)N, bp);
+    else if (algo == 4)
       hipLaunchKernelGGL((gemm_256_p8<FA, FB, 0>), dim3(grid), dim3(512), 0, st, a, b, (uint16_t*)D, sa_inv, sb_inv, (int)K,
                          (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb), (int)(M * ldd * 2),
-                         nullptr, nullptr, (int)M, (int)N);
+                         nullptr, nullptr, (int)M, (int)N, nullptr);
     else
       hipLaunchKernelGGL((gemm_256_p8<FA, FB, 1>), dim3(grid), dim3(512), 0, st, a, b, (uint16_t*)D, sa_inv, sb_inv, (int)K,
                          (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb), (int)(M * ldd * 2),
-                         nullptr, nullptr, (int)M, (int)N);
+                         nullptr, nullptr, (int)M, (int)N, nullptr);
   } else if (algo == 4 && mx) {
     int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
     int grid = tiles_m * tiles_n < num_cus() ? tiles_m * tiles_n : num_cus();
-    hipLaunchKernelGGL((gemm_256_p8<FA, FB, 0, true>), dim3(grid), dim3(512), 0, st, a, b, (uint16_t*)D, sa_inv, sb_inv, (int)K,
-                       (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb), (int)(M * ldd * 2),
-                       (const uint8_t*)SA, (const uint8_t*)SB, (int)M, (int)N);
+    if (bp)
+      hipLaunchKernelGGL((gemm_256_p8<FA, FB, 0, true, true>), dim3(grid), dim3(512), 0, st, a, b, (uint16_t*)D, sa_inv, sb_inv,
+                         (int)K, (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb),
+                         (int)(M * ldd * 2), (const uint8_t*)SA, (const uint8_t*)SB, (int)M, (int)N, bp);
+    else
+      hipLaunchKernelGGL((gemm_256_p8<FA, FB, 0, true, false>), dim3(grid), dim3(512), 0, st, a, b, (uint16_t*)D, sa_inv, sb_inv,
+                         (int)K, (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb),
+                         (int)(M * ldd * 2), (const uint8_t*)SA, (const uint8_t*)SB, (int)M, (int)N, nullptr);
   } else if (algo == 13 && !mx) {
     int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
     hipLaunchKernelGGL((gemm_256_8ph<FA, FB, OUT, 1>), dim3(tiles_m * tiles_n), dim3(512), 0, st, a, b, D, sa_inv, sb_inv,
@@ -800,12 +847,13 @@ static int check_common(const char* who, const void* A, const void* B, void* D, 
 static int pick_algo(int algo, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int out, bool has_bias,
                      const char* who) {
   const bool fast_ok = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && M > 0 && N > 0 && K > 0;
-  // persistent kernel: even K-tile count, bf16 output without bias, 32-bit buffer offsets
-  const bool p8_ok = fast_ok && (K % (2 * BK) == 0) && out == 0 && !has_bias && M * lda < (1LL << 31) &&
+  // persistent kernel: even K-tile count, bf16 output, 32-bit buffer offsets
+  (void)has_bias;
+  const bool p8_ok = fast_ok && (K % (2 * BK) == 0) && out == 0 && M * lda < (1LL << 31) &&
                      N * ldb < (1LL << 31) && M * ldd * 2 < (1LL << 31);
   if (algo == 4 || algo == 15) {
     if (!p8_ok) {
-      set_error("%s: algo %d needs M,N %% 256 == 0, K %% 256 == 0, bf16 output, no bias, operands < 2 GiB", who, algo);
+      set_error("%s: algo %d needs M,N %% 256 == 0, K %% 256 == 0, bf16 output, operands < 2 GiB", who, algo);
       return MI_ERR_SHAPE;
     }
     return algo;

@@ -177,7 +177,7 @@ def test_gemm_fp8_vs_oracle(ops, dev, shape, fa, fb, algo):
     sa, sb = np.float32(1 / 7.3), np.float32(1 / 0.011)
     rng = np.random.default_rng(3)
     bias = O.f32_to_bf16_bits(rng.normal(size=N).astype(np.float32) * 10)
-    for use_bias in ((False,) if algo == 4 else (False, True)):
+    for use_bias in (False, True):
         ref = O.gemm_fp8_tn(a8, b8, fa, fb, sa, sb, bias if use_bias else None, out_f32=True)
         d = ops.gemm_fp8(torch.from_numpy(a8).to(dev), torch.from_numpy(b8).to(dev), _f32(sa, dev), _f32(sb, dev),
                          fa, fb, bias=bits_to_bf16(bias, dev) if use_bias else None, algo=algo)
@@ -292,6 +292,10 @@ def test_gemm_mxfp8_vs_oracle(ops, dev, shape, algo):
     assert (diff <= 7 * 2.0 ** -14 * mag + 1e-5 * np.abs(ref)).all()
     dbf = ops.gemm_mxfp8(t(a8), tT(ae), t(b8), tT(be), algo=algo)
     assert_gemm_close(dbf.float().cpu().numpy(), ref, f"mx gemm {shape}")
+    bias = O.f32_to_bf16_bits(np.random.default_rng(5).normal(size=N).astype(np.float32) * np.abs(ref).mean())
+    refb = O.gemm_mxfp8_tn(a8, ae, b8, be, bias_bf16_bits=bias, out_f32=True)
+    dbb = ops.gemm_mxfp8(t(a8), tT(ae), t(b8), tT(be), bias=bits_to_bf16(bias, dev), algo=algo)
+    assert_gemm_close(dbb.float().cpu().numpy(), refb, f"mx gemm + bias {shape}")
 
 
 # ----------------------------------------------------------------------------------------- fused neighbours (RoPE, K10)
