@@ -70,13 +70,21 @@ class MetaArena:
         self.used += n
         return start
 
+    def reduce(self) -> None:
+        """MAX-all-reduce this iteration's amax row over the data-parallel group: ONE collective for every slot of
+        the arena (TE default `reduce_amax=True`, SURVEY.md 2.4 "FP8 amax all-reduce")."""
+        n = self.used
+        if n == 0 or not self.reduce_amax:
+            return
+        dist = torch.distributed
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(self.hist[0, :n], op=dist.ReduceOp.MAX, group=self.group)
+
     def update(self) -> None:
         if self.used == 0:
             return
         n = self.used
-        if self.reduce_amax and torch.distributed.is_available() and torch.distributed.is_initialized():
-            if torch.distributed.get_world_size(self.group) > 1:
-                torch.distributed.all_reduce(self.hist[0, :n], op=torch.distributed.ReduceOp.MAX, group=self.group)
+        self.reduce()
         ops.scale_update(self.hist[:, :n], self.scale[:n], self.scale_inv[:n], self.fp8_max[:n], self.margin, self.algo)
 
 

@@ -87,9 +87,11 @@ def prepare_model(model: torch.nn.Module, cfg: TrainingConfig) -> torch.nn.Modul
 def wrap_distributed(model: torch.nn.Module, cfg: TrainingConfig, device) -> torch.nn.Module:
     """DistributedWrapper (train_multi_gpu.py:328-510)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or cfg.sharding_mode == "none":
+    if not (dist.is_available() and dist.is_initialized()) or cfg.sharding_mode == "none":
         return model
     mode = cfg.sharding_mode
+    if mode == "auto" and dist.get_world_size() == 1:
+        return model  # an explicit ddp / fsdp_full request is honoured even at world size 1 (rehearsal)
     if mode == "auto":
         mode = "fsdp_full"  # DistributedConfig: auto -> FSDP when more than one GPU (train_multi_gpu.py:81-146)
     if mode == "ddp":
@@ -156,7 +158,7 @@ def setup_distributed():
         device = torch.device("cuda", local)
     else:
         device = torch.device("cpu")
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("LLM_FP8_AMD_FORCE_DIST") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl" if device.type == "cuda" else "gloo", rank=rank, world_size=world,
@@ -176,11 +178,12 @@ def main(argv=None):
     ap.add_argument("--num_steps", type=int, default=10)
     ap.add_argument("--learning_rate", type=float, default=1.41e-5)
     ap.add_argument("--num_hidden_layers", type=int, default=None)
+    ap.add_argument("--vocab_size", type=int, default=None)
     a = ap.parse_args(argv)
     cfg = TrainingConfig(model_name=a.model_name, batch_size=a.batch_size, max_seq_length=a.max_seq_length,
                          mixed_precision=a.mixed_precision, fp8_scenario=a.fp8_scenario, use_te=a.use_te,
                          sharding_mode=a.sharding_mode, learning_rate=a.learning_rate,
-                         num_hidden_layers=a.num_hidden_layers)
+                         num_hidden_layers=a.num_hidden_layers, vocab_size=a.vocab_size)
     rank, local, world, device = setup_distributed()
     torch.manual_seed(cfg.seed + rank)
     model = prepare_model(create_model(cfg, device), cfg)

@@ -1,0 +1,81 @@
+"""World-size-2 gloo tests (CPU): the N > 1 plumbing that needs no FP8 kernels -- the amax MAX-all-reduce of the
+meta arenas, and the DDP / FSDP wrap + train step of the harness on the reference's no-TE bf16 path."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _init(rank, world, port):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+
+
+def _worker(rank, world, port, q):
+    """Both checks in one pair of processes (process start-up dominates the cost of this file)."""
+    _init(rank, world, port)
+    # ---- 1. amax MAX-all-reduce of a meta arena: one collective over the used slots only
+    from llm_fp8_amd.common.recipe import DelayedScaling, Format
+    from llm_fp8_amd.pytorch.fp8 import MetaArena
+    r = DelayedScaling(fp8_format=Format.HYBRID, amax_history_len=4, amax_compute_algo="max")
+    a = MetaArena((r.fp8_format, 4, "max", 0, True), torch.device("cpu"))
+    start = a.alloc(6)
+    a.hist[0, start:start + 6] = torch.tensor([1.0, 5.0, 0.0, 2.0, 9.0, 0.5]) * (rank + 1)
+    a.hist[0, 6:10] = 123.0  # beyond `used`: must not take part
+    a.reduce()
+    row = a.hist[0, :10].tolist()
+    a.reduce_amax = False
+    a.hist[0, 0] = float(rank)
+    a.reduce()
+    single = a.hist[0, 0].item()
+    # ---- 2. the harness' DDP wrap + train step on the reference's no-TE bf16 path, different data per rank
+    from llm_fp8_amd import train
+    import llm_fp8_amd.llama as llama
+    cfg = train.TrainingConfig(model_name="llama-3.2-1b", batch_size=2, max_seq_length=16, mixed_precision="bf16",
+                               use_te=False, sharding_mode="ddp", num_hidden_layers=2, vocab_size=256, learning_rate=1e-2,
+                               num_warmup_steps=0)
+    orig = llama.llama_config
+    llama.llama_config = lambda name, **kw: orig(name, **{**dict(hidden_size=64, intermediate_size=128, num_attention_heads=4,
+                                                               num_key_value_heads=2, head_dim=16, max_position_embeddings=64), **kw})
+    torch.manual_seed(0)
+    device = torch.device("cpu")
+    model = train.wrap_distributed(train.prepare_model(train.create_model(cfg, device), cfg), cfg, device)
+    opt, sched = train.create_optimizer(model, cfg)
+    model.train()
+    g = torch.Generator().manual_seed(100 + rank)
+    losses = [train.train_step(model, train.synthetic_batch(cfg, 256, device, g), opt, sched, cfg).item() for _ in range(3)]
+    flat = torch.cat([p.detach().float().reshape(-1) for p in model.parameters()])
+    q.put((rank, row, single, losses, flat.double().sum().item(), flat.numel()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_amax_allreduce_and_ddp_harness():
+    """FSDP (train_multi_gpu.py's default) cannot be rehearsed here: torch 2.10's FSDP refuses CPU-only processes;
+    tests/test_distributed_gpu.py wraps it on the GPU box instead."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    out = sorted(q.get(timeout=400) for _ in range(2))
+    [p.join(120) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    (_, row0, s0, l0, sum0, n0), (_, row1, s1, l1, sum1, n1) = out
+    assert row0 == row1 == [2.0, 10.0, 0.0, 4.0, 18.0, 1.0, 123.0, 123.0, 123.0, 123.0]
+    assert (s0, s1) == (0.0, 1.0)  # reduce_amax=False leaves the ranks untouched
+    assert n0 == n1 and abs(sum0 - sum1) <= 1e-6 * max(1.0, abs(sum0)), "replicas diverged after 3 steps"
+    assert all(torch.isfinite(torch.tensor(l0 + l1))) and l0 != l1  # ranks really saw different data
