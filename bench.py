@@ -65,6 +65,24 @@ def cpu_baseline(model_name: str, seq: int = 128, layers=(2, 4), timed_steps: in
     }
 
 
+def pmc_traffic(by_tag):
+    """Per-launch fabric bytes of the GEMM kernel from the committed rocprofv3 PMC passes (profiles/), averaged over the
+    launch mix of this run; shapes without a PMC row (lm_head) are left out of the average."""
+    path = os.path.join(ROOT, "profiles", "r01_gemm_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, "no PMC file"
+    tab = json.load(open(path))["sites"]
+    num = den = 0.0
+    for tag, v in by_tag.items():
+        if tag in tab:
+            num += v["launches"] * (tab[tag]["fabric_read_bytes"] + tab[tag]["fabric_write_bytes"])
+            den += v["launches"]
+    if den == 0:
+        return None, "no measured shape in this run"
+    return num / den, ("avg bytes per launch over the decoder GEMM sites, rocprofv3 --pmc FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, "
+                       "separate passes (profiles/r01_gemm_pmc_traffic.json); counts Infinity-Cache hits, i.e. L2-miss traffic")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,8 +166,10 @@ def main():
             g = summ.get(kind)
             if g and g["seconds"] > 0:
                 achieved = g["work"] / g["seconds"] / 1e12
+                traffic, traffic_note = pmc_traffic(g["by_tag"])
                 out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP8_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": achieved / FP8_DENSE_PEAK_TFLOPS, "traffic": None,
+                                   "frac": achieved / FP8_DENSE_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+                                   "avg_algorithmic_bytes_per_launch": g["bytes"] / g["launches"],
                                    "kernel": kind, "launches": g["launches"],
                                    "avg_launch_us": g["seconds"] / g["launches"] * 1e6,
                                    "avg_flop_per_launch": g["work"] / g["launches"],
