@@ -445,24 +445,30 @@ __global__ __launch_bounds__(512, 2) void gemm_256_8ph(const uint8_t* __restrict
 //   block whose rows are whole 128-B lines of the bf16 output.  In the epilogue the two 4-column pieces
 //   a lane holds per (mh, i, nh) are widened to 8 contiguous columns with v_permlane16_swap and stored
 //   as one dwordx4 (16 rows x 64 B per instruction, 16 stores per wave and tile).
-constexpr int kEpiStores = 16;
-
-// rows of half-tile piece p (16w + 8i + lr) -> row inside the 256-row tile
-__device__ __forceinline__ int a_half_row(int h, int local) { return (local >> 6) * 128 + h * 64 + (local & 63); }
-__device__ __forceinline__ int b_half_row(int h, int local) { return (local >> 5) * 64 + h * 32 + (local & 31); }
+// Tile shapes: a wave owns (4 + MA1) x (2 + NB1) MFMA tiles; MA1 in {4, 2} and NB1 in {2, 1} give workgroup tiles of
+// 256 or 192 rows x 256 or 192 columns.  The 192 variants exist for wave quantisation: an 8192x3072 output is 384
+// tiles of 256x256 = 1.5 rounds on 256 CUs (the second round half empty) but 512 tiles of 256x192 = exactly 2 rounds of
+// 0.75-size tiles.  Same 4-phase pipeline; phases 1-2 (and 2-3) just issue fewer MFMAs and the second half-tiles
+// (A1: 2*16*MA1 rows, B1: 4*16*NB1 rows) are smaller.
 
 // LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... offen lds): SGPR resource + per-lane 32-bit
 // voffset (constant for the whole kernel) + uniform soffset per stage -> no per-stage VALU address math.
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
-__device__ __forceinline__ void stage2(rsrc_t rs, const int (&voff)[2], int soff, uint8_t* lds_half, int wave) {
+template <int NP>
+__device__ __forceinline__ void stage_n(rsrc_t rs, const int* voff, int soff, uint8_t* lds_half, int wave) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds_half + (wave * 2 + i) * 1024), 16, voff[i], soff, 0, 0);
+  for (int i = 0; i < NP; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds_half + (wave * NP + i) * 1024), 16, voff[i], soff, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // Requires K % 256 == 0 (an even number of K-tiles, so every tile starts on LDS buffer 0) and
 // operand / output footprints < 2^31 bytes (32-bit buffer offsets); the host dispatcher checks both.
-template <int FA, int FB, int ABL = 0, bool MX = false, bool BIAS = false>
+template <int FA, int FB, int ABL = 0, bool MX = false, bool BIAS = false, int MA1 = 4, int NB1 = 2>
 __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
                                                       uint16_t* __restrict__ D, const float* __restrict__ sa_inv,
                                                       const float* __restrict__ sb_inv, int K, int lda, int ldb,
@@ -470,10 +476,15 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
                                                       int d_bytes, const uint8_t* __restrict__ SA,
                                                       const uint8_t* __restrict__ SB, int M, int N,
                                                       const uint16_t* __restrict__ bias) {
+  constexpr int RA0 = 64, RA1 = 16 * MA1, RB0 = 32, RB1 = 16 * NB1;  // rows of A / B per wave in half 0 / 1
+  constexpr int TBM = 2 * (RA0 + RA1), TBN = 4 * (RB0 + RB1);        // workgroup tile
+  constexpr int nA1 = MA1 / 2, nB1 = NB1;                            // LDS-DMA pieces per wave of the second halves
+  constexpr int EX = (MX ? 1 : 0) + (BIAS ? 1 : 0);                  // extra LDS-DMA ops per K-tile (head of phase 0)
+  constexpr int W = nA1 + nB1 + 4;                                   // younger ops allowed at the p3 wait (8 for 256x256)
+  constexpr int NST = (4 + MA1) * 2;                                 // epilogue stores per wave and tile
   // behind the operand buffers: 4 KiB of E8M0 scales (MX: 2 slots x {A, B} x 4 k-blocks x 256 rows) and 4 KiB of
   // bias windows (BIAS: 2 slots x 8 waves x 256 B)
   __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes + ((MX || BIAS) ? 8192 : 0)];
-  constexpr int EX = (MX ? 1 : 0) + (BIAS ? 1 : 0);  // extra LDS-DMA ops per K-tile, issued at the head of phase 0
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -491,21 +502,21 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   const int s_rows = s_is_b ? N : M;
   const rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(MX ? (s_is_b ? SB : SA) : A), 0, MX ? (K / 32) * s_rows : 0, 0x00020000);
   uint8_t* const sbuf = lds + kLdsBytes;  // [slot][operand][4][256]
-  // bias: every K-tile each wave re-fetches the 256-byte window that starts at its own 64 columns of cursor 1's tile
-  // (one dword per lane; reads past N return 0 through the descriptor's range check) -> uniform vmcnt accounting
-  const rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)(BIAS ? (const void*)bias : (const void*)A), 0, BIAS ? N * 2 : 0, 0x00020000);
-  uint8_t* const bbuf = lds + kLdsBytes + 4096;  // [slot][wave][256 B]
-  auto stage_bias = [&](int slot, int col0) {
-    if (BIAS)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBias, LDS_PTR(bbuf + (slot * 8 + wave) * 256), 4, lane * 4,
-                                               (col0 + wc * 64) * 2, 0, 0);
-  };
   auto stage_scales = [&](int slot, int kt, int row0a, int row0b) {
     if (MX) {
       const int soff = (kt * 4 + (wave & 3)) * s_rows + (s_is_b ? row0b : row0a);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, LDS_PTR(sbuf + slot * 2048 + (wave >> 2) * 1024 + (wave & 3) * 256), 4,
                                                lane * 4, soff, 0, 0);
     }
+  };
+  // bias: every K-tile each wave re-fetches the 256-byte window that starts at its own columns of cursor 1's tile
+  // (one dword per lane; reads past N return 0 through the descriptor's range check) -> uniform vmcnt accounting
+  const rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)(BIAS ? (const void*)bias : (const void*)A), 0, BIAS ? N * 2 : 0, 0x00020000);
+  uint8_t* const bbuf = lds + kLdsBytes + 4096;  // [slot][wave][256 B]
+  auto stage_bias = [&](int slot, int col0) {
+    if (BIAS)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBias, LDS_PTR(bbuf + (slot * 8 + wave) * 256), 4, lane * 4,
+                                               (col0 + wc * (RB0 + RB1)) * 2, 0, 0);
   };
   v4f acc[2][4][2][2];
 #pragma unroll
@@ -517,31 +528,41 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[a][i][b][j] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-  // per-lane staging offsets (half h = 0; h = 1 adds a uniform 64*lda / 32*ldb)
-  int a_voff[2], b_voff[2];
+  // per-lane staging offsets.  Half-tile local row -> tile row: the rows of wave-row wr' (A) / wave-col wc' (B) of
+  // half h are contiguous in the tile, so a wave's output block is contiguous (whole 128-B lines per row).
+  int a0_voff[2], a1_voff[nA1], b0_voff[2], b1_voff[nB1];
   {
     const int lr = lane >> 3, lc = lane & 7;
     const int chunk = (lc ^ swz_f(lr)) * 16;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int local = (wave * 2 + i) * 8 + lr;
-      a_voff[i] = a_half_row(0, local) * lda + chunk;
-      b_voff[i] = b_half_row(0, local) * ldb + chunk;
+      const int local = (wave * 2 + i) * 8 + lr;  // half 0: 128 rows, 16 pieces
+      a0_voff[i] = ((local / RA0) * (RA0 + RA1) + local % RA0) * lda + chunk;
+      b0_voff[i] = ((local / RB0) * (RB0 + RB1) + local % RB0) * ldb + chunk;
+    }
+#pragma unroll
+    for (int i = 0; i < nA1; ++i) {
+      const int local = (wave * nA1 + i) * 8 + lr;  // half 1 of A: 2*RA1 rows
+      a1_voff[i] = ((local / RA1) * (RA0 + RA1) + RA0 + local % RA1) * lda + chunk;
+    }
+#pragma unroll
+    for (int i = 0; i < nB1; ++i) {
+      const int local = (wave * nB1 + i) * 8 + lr;  // half 1 of B: 4*RB1 rows
+      b1_voff[i] = ((local / RB1) * (RB0 + RB1) + RB0 + local % RB1) * ldb + chunk;
     }
   }
-  const int a_h1 = 64 * lda, b_h1 = 32 * ldb;
 
   // pipeline cursors (wave-uniform byte offsets of the (tile, K-tile) of step s+1 / s+2, clamped to the last step)
   const int total = my_tiles * nk;
-  int ra_1 = 0, rb_1 = 0;  // row origins (tm*256, tn*256) of cursor 1's tile, for the MX scale stage
   auto tile_origin = [&](int ti, int& oa, int& ob, int& ra, int& rb) {
     int tm, tn;
     tile_of_block(bid + ti * G, ntiles, tiles_m, tiles_n, tm, tn);
-    oa = tm * BM * lda;
-    ob = tn * BN * ldb;
-    ra = tm * BM;
-    rb = tn * BN;
+    ra = tm * TBM;
+    rb = tn * TBN;
+    oa = ra * lda;
+    ob = rb * ldb;
   };
+  int ra_1 = 0, rb_1 = 0;
   int oa_1, ob_1, oa_2, ob_2, ti_1 = 0, kt_1 = 0, ti_2 = 0, kt_2 = 0;
   int oa_0, ob_0, ra_0, rb_0, ra_2, rb_2;
   tile_origin(0, oa_0, ob_0, ra_0, rb_0);
@@ -567,12 +588,12 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   // prologue: step 0 complete, (step 1: A0, B0) in flight
   stage_scales(0, 0, ra_0, rb_0);
   stage_bias(0, rb_0);
-  stage2(rsA, a_voff, oa_0, buf0 + kOffA0, wave);
-  stage2(rsB, b_voff, ob_0, buf0 + kOffB0, wave);
-  stage2(rsB, b_voff, ob_0 + b_h1, buf0 + kOffB1, wave);
-  stage2(rsA, a_voff, oa_0 + a_h1, buf0 + kOffA1, wave);
-  stage2(rsA, a_voff, oa_1 + kt_1 * BK, buf1 + kOffA0, wave);
-  stage2(rsB, b_voff, ob_1 + kt_1 * BK, buf1 + kOffB0, wave);
+  stage_n<2>(rsA, a0_voff, oa_0, buf0 + kOffA0, wave);
+  stage_n<2>(rsB, b0_voff, ob_0, buf0 + kOffB0, wave);
+  stage_n<nB1>(rsB, b1_voff, ob_0, buf0 + kOffB1, wave);
+  stage_n<nA1>(rsA, a1_voff, oa_0, buf0 + kOffA1, wave);
+  stage_n<2>(rsA, a0_voff, oa_1 + kt_1 * BK, buf1 + kOffA0, wave);
+  stage_n<2>(rsB, b0_voff, ob_1 + kt_1 * BK, buf1 + kOffB0, wave);
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
@@ -582,90 +603,81 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   int as_[4] = {kUnitScale, kUnitScale, kUnitScale, kUnitScale}, b0s[2] = {kUnitScale, kUnitScale}, b1s[2] = {kUnitScale, kUnitScale};
   const int sfr = lane & 15, sfq = lane >> 4;
   int s = 0;  // current step
-  // one K-tile = 4 phases.  `after_epi` (uniform): this is the first K-tile behind an epilogue, so the 16 stores
-  // sit between the awaited loads and the younger ones -> wait with vmcnt(8 + 16).
-  // MX / BIAS each issue one more LDS-DMA per K-tile (first ops of phase 0), so phases 0-2 wait with 8 + EX (+16).
-#define MI_WAIT_SYNC(after_epi, P3)                                                                    \
-  if (EX == 2 && !(P3)) {                                                                              \
-    if (after_epi) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");                                   \
-    else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                             \
-  } else if (EX == 1 && !(P3)) {                                                                       \
-    if (after_epi) asm volatile("s_waitcnt vmcnt(25)" ::: "memory");                                   \
-    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                                              \
-  } else {                                                                                             \
-    if (after_epi) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                                   \
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                              \
-  }                                                                                                    \
+  // One K-tile = 4 phases.  Waits: phases 0-2 allow W + EX younger LDS-DMA ops, phase 3 allows W; `after_epi`
+  // (uniform): first K-tile behind an epilogue, whose NST stores sit between the awaited loads and the younger ones.
+#define MI_WAIT_SYNC(after_epi, P3)                                    \
+  if (after_epi) wait_vmcnt<W + ((P3) ? 0 : EX) + NST>();              \
+  else wait_vmcnt<W + ((P3) ? 0 : EX)>();                              \
   __builtin_amdgcn_s_barrier();                                        \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   \
   __builtin_amdgcn_sched_barrier(0);                                   \
   __builtin_amdgcn_s_setprio(1);
-#define MI_PIN8(EXPR)                                                  \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i)                        \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(EXPR));
+#define MI_PIN(NI, NJ, EXPR)                                           \
+  _Pragma("unroll") for (int i = 0; i < NI; ++i)                       \
+  _Pragma("unroll") for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(EXPR));
   auto ktile = [&](uint8_t* cur, uint8_t* oth, bool after_epi, int slot) {
     const uint8_t* sc = sbuf + slot * 2048 + sfq * 256 + sfr;  // + operand*1024 + tile row of the fragment
     const int sa1 = oa_1 + kt_1 * BK, sb1 = ob_1 + kt_1 * BK;
     const int sa2 = oa_2 + kt_2 * BK, sb2 = ob_2 + kt_2 * BK;
-    // ---- phase 0
+    // ---- phase 0: C[0][*][0][*]
 #pragma unroll
     for (int j = 0; j < 2; ++j) b0f[j] = read_frag(cur + kOffB0, wc * 2 + j, lane);
 #pragma unroll
     for (int i = 0; i < 4; ++i) af[i] = read_frag(cur + kOffA0, wr * 4 + i, lane);
     if (MX) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b0s[j] = sc[1024 + wc * 64 + j * 16];
+      for (int j = 0; j < 2; ++j) b0s[j] = sc[1024 + wc * (RB0 + RB1) + j * 16];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) as_[i] = sc[wr * 128 + i * 16];
+      for (int i = 0; i < 4; ++i) as_[i] = sc[wr * (RA0 + RA1) + i * 16];
     }
     stage_scales(slot ^ 1, kt_1, ra_1, rb_1);
     stage_bias(ti_1 & 1, rb_1);
-    stage2(rsB, b_voff, sb1 + b_h1, oth + kOffB1, wave);
+    stage_n<nB1>(rsB, b1_voff, sb1, oth + kOffB1, wave);
     MI_WAIT_SYNC(after_epi, false)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[0][i][0][j] = mfma_ba<FA, FB>(af[i], b0f[j], acc[0][i][0][j], as_[i], b0s[j]);
-    MI_PIN8(acc[0][i][0][j])
+    MI_PIN(4, 2, acc[0][i][0][j])
     MI_PHASE_END();
-    // ---- phase 1
+    // ---- phase 1: C[0][*][1][*]
 #pragma unroll
-    for (int j = 0; j < 2; ++j) b1f[j] = read_frag(cur + kOffB1, wc * 2 + j, lane);
+    for (int j = 0; j < NB1; ++j) b1f[j] = read_frag(cur + kOffB1, wc * NB1 + j, lane);
     if (MX) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b1s[j] = sc[1024 + wc * 64 + 32 + j * 16];
+      for (int j = 0; j < NB1; ++j) b1s[j] = sc[1024 + wc * (RB0 + RB1) + RB0 + j * 16];
     }
-    stage2(rsA, a_voff, sa1 + a_h1, oth + kOffA1, wave);
+    stage_n<nA1>(rsA, a1_voff, sa1, oth + kOffA1, wave);
     MI_WAIT_SYNC(after_epi, false)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[0][i][1][j] = mfma_ba<FA, FB>(af[i], b1f[j], acc[0][i][1][j], as_[i], b1s[j]);
-    MI_PIN8(acc[0][i][1][j])
+      for (int j = 0; j < NB1; ++j) acc[0][i][1][j] = mfma_ba<FA, FB>(af[i], b1f[j], acc[0][i][1][j], as_[i], b1s[j]);
+    MI_PIN(4, NB1, acc[0][i][1][j])
     MI_PHASE_END();
-    // ---- phase 2
+    // ---- phase 2: C[1][*][1][*]
 #pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = read_frag(cur + kOffA1, wr * 4 + i, lane);
+    for (int i = 0; i < MA1; ++i) af[i] = read_frag(cur + kOffA1, wr * MA1 + i, lane);
     if (MX) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) as_[i] = sc[wr * 128 + 64 + i * 16];
+      for (int i = 0; i < MA1; ++i) as_[i] = sc[wr * (RA0 + RA1) + RA0 + i * 16];
     }
-    stage2(rsA, a_voff, sa2, cur + kOffA0, wave);
+    stage_n<2>(rsA, a0_voff, sa2, cur + kOffA0, wave);
     MI_WAIT_SYNC(after_epi, false)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MA1; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[1][i][1][j] = mfma_ba<FA, FB>(af[i], b1f[j], acc[1][i][1][j], as_[i], b1s[j]);
-    MI_PIN8(acc[1][i][1][j])
+      for (int j = 0; j < NB1; ++j) acc[1][i][1][j] = mfma_ba<FA, FB>(af[i], b1f[j], acc[1][i][1][j], as_[i], b1s[j]);
+    MI_PIN(MA1, NB1, acc[1][i][1][j])
     MI_PHASE_END();
-    // ---- phase 3
-    stage2(rsB, b_voff, sb2, cur + kOffB0, wave);
+    // ---- phase 3: C[1][*][0][*]
+    stage_n<2>(rsB, b0_voff, sb2, cur + kOffB0, wave);
     MI_WAIT_SYNC(after_epi, true)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MA1; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[1][i][0][j] = mfma_ba<FA, FB>(af[i], b0f[j], acc[1][i][0][j], as_[i], b0s[j]);
-    MI_PIN8(acc[1][i][0][j])
+    MI_PIN(MA1, 2, acc[1][i][0][j])
     MI_PHASE_END();
     // cursors follow the step
     ++s;
@@ -675,19 +687,19 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
 
   const int fr = lane & 15, fq = lane >> 4;
   const int ecol = (fq & 1) * 16 + (fq >> 1) * 8;  // column of this lane's 8-wide piece after the permlane16 swap
-  const int d_voff = ((wr * 128 + fr) * ldd + wc * 64 + ecol) * 2;  // bytes, within the tile
+  const int d_voff = ((wr * (RA0 + RA1) + fr) * ldd + wc * (RB0 + RB1)) * 2;  // bytes, within the tile
   auto epilogue = [&](int ti) {
     int tm, tn;
     tile_of_block(bid + ti * G, ntiles, tiles_m, tiles_n, tm, tn);
-    const int d_tile = (tm * BM * ldd + tn * BN) * 2;  // uniform, bytes
+    const int d_tile = (tm * TBM * ldd + tn * TBN) * 2;  // uniform, bytes
     float bv[2][2][4];
     if (BIAS) {  // this wave's own LDS-DMA data: covered by the vmcnt waits of the last K-tile, no barrier needed
       const uint8_t* bp = bbuf + ((ti & 1) * 8 + wave) * 256 + fq * 8;
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const uint2 w = *reinterpret_cast<const uint2*>(bp + (b * 32 + j * 16) * 2);
+        for (int j = 0; j < (b == 0 ? 2 : NB1); ++j) {
+          const uint2 w = *reinterpret_cast<const uint2*>(bp + (b * RB0 + j * 16) * 2);
           bv[b][j][0] = __uint_as_float(w.x << 16);
           bv[b][j][1] = __uint_as_float(w.x & 0xFFFF0000u);
           bv[b][j][2] = __uint_as_float(w.y << 16);
@@ -697,30 +709,47 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < (a == 0 ? 4 : MA1); ++i)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          v4f v0 = acc[a][i][b][0] * alpha, v1 = acc[a][i][b][1] * alpha;
-          if (BIAS) {
+          const int soff = d_tile + ((a * RA0 + i * 16) * ldd + b * RB0) * 2;
+          if (b == 0 || NB1 == 2) {
+            v4f v0 = acc[a][i][b][0] * alpha, v1 = acc[a][i][b][1] * alpha;
+            if (BIAS) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              v0[e] += bv[b][0][e];
-              v1[e] += bv[b][1][e];
+              for (int e = 0; e < 4; ++e) {
+                v0[e] += bv[b][0][e];
+                v1[e] += bv[b][1][e];
+              }
             }
-          }
-          u32 p0x = pack_bf16x2(v0[0], v0[1]), p0y = pack_bf16x2(v0[2], v0[3]);
-          u32 p1x = pack_bf16x2(v1[0], v1[1]), p1y = pack_bf16x2(v1[2], v1[3]);
-          auto sx = __builtin_amdgcn_permlane16_swap(p0x, p1x, false, false);
-          auto sy = __builtin_amdgcn_permlane16_swap(p0y, p1y, false, false);
-          v4i o = {(int)sx[0], (int)sy[0], (int)sx[1], (int)sy[1]};
-          if (ABL == 1) {
-            asm volatile("" ::"v"(o));
-          } else {
-            __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)o, rsD, d_voff, d_tile + ((a * 64 + i * 16) * ldd + b * 32) * 2, 0);
-            // hipcc (ROCm 7.2) lets the next VALU overwrite the data registers of this 16-byte store (SGPR-offset form)
-            // with no wait state: lanes 12-15 of every 16-lane row then stored the NEXT block's unconverted fp32
-            // (seen on MI355X, tools/debug_gemm.py).  Keep the registers live across the required wait states.
-            asm volatile("s_nop 1" ::"v"(o) : "memory");
+            u32 p0x = pack_bf16x2(v0[0], v0[1]), p0y = pack_bf16x2(v0[2], v0[3]);
+            u32 p1x = pack_bf16x2(v1[0], v1[1]), p1y = pack_bf16x2(v1[2], v1[3]);
+            auto sx = __builtin_amdgcn_permlane16_swap(p0x, p1x, false, false);
+            auto sy = __builtin_amdgcn_permlane16_swap(p0y, p1y, false, false);
+            v4i o = {(int)sx[0], (int)sy[0], (int)sx[1], (int)sy[1]};
+            if (ABL == 1) {
+              asm volatile("" ::"v"(o));
+            } else {
+              __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)o, rsD, d_voff + ecol * 2, soff, 0);
+              // hipcc (ROCm 7.2) lets the next VALU overwrite the data registers of this 16-byte store (SGPR-offset
+              // form) with no wait state: lanes 12-15 of every 16-lane row then stored the NEXT block's unconverted
+              // fp32 (seen on MI355X, tools/debug_gemm.py).  Keep the registers live across the required wait states.
+              asm volatile("s_nop 1" ::"v"(o) : "memory");
+            }
+          } else {  // NB1 == 1: a single 16-column tile in the second column block -> 4 columns (8 B) per lane
+            v4f v0 = acc[a][i][1][0] * alpha;
+            if (BIAS) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v0[e] += bv[1][0][e];
+            }
+            typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+            v2u o = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3])};
+            if (ABL == 1) {
+              asm volatile("" ::"v"(o));
+            } else {
+              __builtin_amdgcn_raw_buffer_store_b64(o, rsD, d_voff + fq * 8, soff, 0);
+              asm volatile("s_nop 1" ::"v"(o) : "memory");
+            }
           }
           acc[a][i][b][0] = (v4f){0.f, 0.f, 0.f, 0.f};
           acc[a][i][b][1] = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -741,8 +770,9 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   if (wr == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef MI_WAIT_SYNC
-#undef MI_PIN8
+#undef MI_PIN
 }
+
 
 static int num_cus() {
   static int n = 0;  // benign race: every thread computes the same value
@@ -753,6 +783,74 @@ static int num_cus() {
     else n = 256;
   }
   return n;
+}
+
+// Tile shape for the persistent kernel: minimise rounds x tile area / efficiency over the shapes that divide M, N.
+// cfg: 0 = 256x256, 1 = 256x192, 2 = 192x256, 3 = 192x192.
+static int pick_tile_cfg(int64_t M, int64_t N, int64_t K) {
+  static const int bm[4] = {256, 256, 192, 192}, bn[4] = {256, 192, 256, 192};
+  static const double eff[4] = {1.0, 0.90, 0.90, 0.80};  // measured relative MFMA-time efficiency of the shorter phases
+  const int ncu = num_cus();
+  int best = -1;
+  double best_cost = 0;
+  // Measured on MI355X (tools/bench_kernels.py --which tiles): the 192 shapes pay off when a round is long (K >= 4096);
+  // at K = 3072 their extra epilogues cost more than the half-empty last round of 256x256 tiles.
+  if (K < 4096 && M % 256 == 0 && N % 256 == 0) return 0;
+  for (int c = 0; c < 4; ++c) {
+    if (M % bm[c] || N % bn[c]) continue;
+    const int64_t tiles = (M / bm[c]) * (N / bn[c]);
+    const int64_t rounds = (tiles + ncu - 1) / ncu;
+    const double cost = (double)rounds * bm[c] * bn[c] / eff[c];
+    if (best < 0 || cost < best_cost * 0.97) {  // prefer the larger tile unless the gain is > 3 %
+      best = c;
+      best_cost = cost;
+    }
+  }
+  return best;
+}
+
+template <int FA, int FB, bool MX, bool BIAS, int ABL, int MA1, int NB1>
+static void launch_p8_cfg(const uint8_t* a, const uint8_t* b, uint16_t* D, const float* sa_inv, const float* sb_inv,
+                          const uint8_t* SA, const uint8_t* SB, const uint16_t* bias, int64_t M, int64_t N, int64_t K,
+                          int64_t lda, int64_t ldb, int64_t ldd, hipStream_t st) {
+  constexpr int TBM = 2 * (64 + 16 * MA1), TBN = 4 * (32 + 16 * NB1);
+  const int tiles_m = (int)(M / TBM), tiles_n = (int)(N / TBN);
+  const int grid = tiles_m * tiles_n < num_cus() ? tiles_m * tiles_n : num_cus();
+  hipLaunchKernelGGL((gemm_256_p8<FA, FB, ABL, MX, BIAS, MA1, NB1>), dim3(grid), dim3(512), 0, st, a, b, D, sa_inv, sb_inv, (int)K,
+                     (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb), (int)(M * ldd * 2), SA, SB,
+                     (int)M, (int)N, bias);
+}
+
+template <int FA, int FB>
+static int launch_p8(const uint8_t* a, const uint8_t* b, uint16_t* D, const float* sa_inv, const float* sb_inv,
+                     const uint8_t* SA, const uint8_t* SB, const uint16_t* bias, int64_t M, int64_t N, int64_t K, int64_t lda,
+                     int64_t ldb, int64_t ldd, int algo, bool mx, hipStream_t st) {
+  int cfg = (algo >= 40 && algo <= 43) ? algo - 40 : pick_tile_cfg(M, N, K);
+  static const int bm[4] = {256, 256, 192, 192}, bn[4] = {256, 192, 256, 192};
+  if (cfg < 0 || M % bm[cfg] || N % bn[cfg]) {
+    set_error("mi_gemm: no persistent tile shape divides %lld x %lld", (long long)M, (long long)N);
+    return MI_ERR_SHAPE;
+  }
+#define MI_P8(MXv, BIASv, ABLv, MA1v, NB1v) \
+  launch_p8_cfg<FA, FB, MXv, BIASv, ABLv, MA1v, NB1v>(a, b, D, sa_inv, sb_inv, SA, SB, bias, M, N, K, lda, ldb, ldd, st)
+#define MI_P8_CFG(MXv, BIASv, ABLv)                                 \
+  switch (cfg) {                                                    \
+    case 0: MI_P8(MXv, BIASv, ABLv, 4, 2); break;                   \
+    case 1: MI_P8(MXv, BIASv, ABLv, 4, 1); break;                   \
+    case 2: MI_P8(MXv, BIASv, ABLv, 2, 2); break;                   \
+    default: MI_P8(MXv, BIASv, ABLv, 2, 1); break;                  \
+  }
+  if (algo == 15) {
+    MI_P8_CFG(false, false, 1)
+  } else if (mx) {
+    if (bias) { MI_P8_CFG(true, true, 0) } else { MI_P8_CFG(true, false, 0) }
+  } else {
+    if (bias) { MI_P8_CFG(false, true, 0) } else { MI_P8_CFG(false, false, 0) }
+  }
+#undef MI_P8_CFG
+#undef MI_P8
+  MI_CHECK_LAUNCH("mi_gemm (persistent) launch");
+  return MI_OK;
 }
 
 template <int FA, int FB, int OUT>
@@ -769,32 +867,9 @@ static int launch_fmt(const void* A, const void* B, void* D, const float* sa_inv
     int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
     hipLaunchKernelGGL((gemm_256_8ph<FA, FB, OUT>), dim3(tiles_m * tiles_n), dim3(512), 0, st, a, b, D, sa_inv, sb_inv,
                        bp, (int)M, (int)N, (int)K, lda, ldb, ldd, tiles_m, tiles_n);
-  } else if ((algo == 4 || algo == 15) && !mx) {
-    int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
-    int grid = tiles_m * tiles_n < num_cus() ? tiles_m * tiles_n : num_cus();
-    if (algo == 4 && bp)
-      hipLaunchKernelGGL((gemm_256_p8<FA, FB, 0, false, true>), dim3(grid), dim3(512), 0, st, a, b, (uint16_t*)D, sa_inv, sb_inv,
-                         (int)K, (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb),
-                         (int)(M * ldd * 2), nullptr, nullptr, (int)M, (int)N, bp);
-    else if (algo == 4)
-      hipLaunchKernelGGL((gemm_256_p8<FA, FB, 0>), dim3(grid), dim3(512), 0, st, a, b, (uint16_t*)D, sa_inv, sb_inv, (int)K,
-                         (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb), (int)(M * ldd * 2),
-                         nullptr, nullptr, (int)M, (int)N, nullptr);
-    else
-      hipLaunchKernelGGL((gemm_256_p8<FA, FB, 1>), dim3(grid), dim3(512), 0, st, a, b, (uint16_t*)D, sa_inv, sb_inv, (int)K,
-                         (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb), (int)(M * ldd * 2),
-                         nullptr, nullptr, (int)M, (int)N, nullptr);
-  } else if (algo == 4 && mx) {
-    int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
-    int grid = tiles_m * tiles_n < num_cus() ? tiles_m * tiles_n : num_cus();
-    if (bp)
-      hipLaunchKernelGGL((gemm_256_p8<FA, FB, 0, true, true>), dim3(grid), dim3(512), 0, st, a, b, (uint16_t*)D, sa_inv, sb_inv,
-                         (int)K, (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb),
-                         (int)(M * ldd * 2), (const uint8_t*)SA, (const uint8_t*)SB, (int)M, (int)N, bp);
-    else
-      hipLaunchKernelGGL((gemm_256_p8<FA, FB, 0, true, false>), dim3(grid), dim3(512), 0, st, a, b, (uint16_t*)D, sa_inv, sb_inv,
-                         (int)K, (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb),
-                         (int)(M * ldd * 2), (const uint8_t*)SA, (const uint8_t*)SB, (int)M, (int)N, nullptr);
+  } else if (algo == 4 || algo == 15 || (algo >= 40 && algo <= 43)) {
+    return launch_p8<FA, FB>(a, b, (uint16_t*)D, sa_inv, sb_inv, (const uint8_t*)SA, (const uint8_t*)SB, bp, M, N, K, lda, ldb, ldd,
+                             algo, mx, st);
   } else if (algo == 13 && !mx) {
     int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
     hipLaunchKernelGGL((gemm_256_8ph<FA, FB, OUT, 1>), dim3(tiles_m * tiles_n), dim3(512), 0, st, a, b, D, sa_inv, sb_inv,
@@ -849,11 +924,12 @@ static int pick_algo(int algo, int64_t M, int64_t N, int64_t K, int64_t lda, int
   const bool fast_ok = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && M > 0 && N > 0 && K > 0;
   // persistent kernel: even K-tile count, bf16 output, 32-bit buffer offsets
   (void)has_bias;
-  const bool p8_ok = fast_ok && (K % (2 * BK) == 0) && out == 0 && M * lda < (1LL << 31) &&
-                     N * ldb < (1LL << 31) && M * ldd * 2 < (1LL << 31);
-  if (algo == 4 || algo == 15) {
+  const bool p8_ok = (M % 256 == 0 || M % 192 == 0) && (N % 256 == 0 || N % 192 == 0) && M > 0 && N > 0 && K > 0 &&
+                     (K % (2 * BK) == 0) && out == 0 && M * lda < (1LL << 31) && N * ldb < (1LL << 31) &&
+                     M * ldd * 2 < (1LL << 31);
+  if (algo == 4 || algo == 15 || (algo >= 40 && algo <= 43)) {
     if (!p8_ok) {
-      set_error("%s: algo %d needs M,N %% 256 == 0, K %% 256 == 0, bf16 output, operands < 2 GiB", who, algo);
+      set_error("%s: algo %d needs M,N %% 256 (or 192) == 0, K %% 256 == 0, bf16 output, operands < 2 GiB", who, algo);
       return MI_ERR_SHAPE;
     }
     return algo;
@@ -893,13 +969,13 @@ extern "C" int mi_gemm_mxfp8(const void* A, const void* SA, const void* B, const
   if (rc != MI_OK) return rc;
   MI_CHECK_ARG(SA && SB, "mi_gemm_mxfp8: null scale pointer");
   MI_CHECK_ARG(K % 32 == 0, "mi_gemm_mxfp8: K must be a multiple of 32");
-  MI_CHECK_ARG(algo == 0 || algo == 1 || algo == 4, "mi_gemm_mxfp8: algo must be 0, 1 or 4");
+  MI_CHECK_ARG(algo == 0 || algo == 1 || algo == 4 || (algo >= 40 && algo <= 43), "mi_gemm_mxfp8: algo must be 0, 1, 4 or 40-43");
   if (M == 0 || N == 0) return MI_OK;
   int a = algo == 0 ? 4 : algo;
-  if (a == 4) {
-    a = mi::pick_algo(4, M, N, K, K, K, N, out_dtype, bias_bf16 != nullptr, "mi_gemm_mxfp8");
+  if (a != 1) {
+    a = mi::pick_algo(a, M, N, K, K, K, N, out_dtype, bias_bf16 != nullptr, "mi_gemm_mxfp8");
     if (a < 0) {
-      if (algo == 4) return a;
+      if (algo != 0) return a;
       a = 1;  // auto: fall back to the generic kernel
     }
   }

@@ -157,21 +157,25 @@ def assert_mfma_close(got, ref, a8, b8, fa, fb, alpha):
     assert np.sqrt(np.mean(diff ** 2)) <= 2.0 ** -12 * np.sqrt(np.mean(mag ** 2))
 
 
-GEMM_SHAPES = [(256, 256, 256), (512, 768, 640), (2048, 2304, 512), (4096, 4352, 256), (64, 96, 128), (16, 16, 16), (8, 24, 48), (200, 136, 400), (256, 256, 128), (256, 512, 384),
+GEMM_SHAPES = [(256, 256, 256), (512, 768, 640), (768, 384, 512), (1536, 1920, 256), (192, 192, 256), (2048, 2304, 512), (4096, 4352, 256), (64, 96, 128), (16, 16, 16), (8, 24, 48), (200, 136, 400), (256, 256, 128), (256, 512, 384),
                (512, 256, 3072), (256, 5120, 3072), (768, 1024, 256)]
 
 
 @pytest.mark.parametrize("shape", GEMM_SHAPES)
 @pytest.mark.parametrize("fa,fb", [(O.E4M3, O.E4M3), (O.E5M2, O.E4M3), (O.E4M3, O.E5M2), (O.E5M2, O.E5M2)])
-@pytest.mark.parametrize("algo", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("algo", [0, 1, 2, 3, 4, 41, 42, 43])
 def test_gemm_fp8_vs_oracle(ops, dev, shape, fa, fb, algo):
     M, N, K = shape
     if algo == 1 and M * N * K > 256 * 512 * 3072:
         pytest.skip("generic path covered at smaller sizes")
     if algo in (2, 3) and (M % 256 or N % 256 or K % 128):
         pytest.skip("fast kernels need 256/256/128-aligned shapes")
-    if algo == 4 and (M % 256 or N % 256 or K % 256):
-        pytest.skip("persistent kernel needs 256/256/256-aligned shapes")
+    if algo == 4 and ((M % 256 and M % 192) or (N % 256 and N % 192) or K % 256):
+        pytest.skip("persistent kernel needs 256- or 192-aligned M, N and 256-aligned K")
+    if algo in (41, 42, 43):
+        bm, bn = {41: (256, 192), 42: (192, 256), 43: (192, 192)}[algo]
+        if M % bm or N % bn or K % 256:
+            pytest.skip("tile shape does not divide the problem")
     a8 = _rand_fp8((M, K), fa, 1 + M, 4.0 if fa == O.E4M3 else 64.0)
     b8 = _rand_fp8((N, K), fb, 2 + N, 4.0 if fb == O.E4M3 else 64.0)
     sa, sb = np.float32(1 / 7.3), np.float32(1 / 0.011)
@@ -182,7 +186,7 @@ def test_gemm_fp8_vs_oracle(ops, dev, shape, fa, fb, algo):
         d = ops.gemm_fp8(torch.from_numpy(a8).to(dev), torch.from_numpy(b8).to(dev), _f32(sa, dev), _f32(sb, dev),
                          fa, fb, bias=bits_to_bf16(bias, dev) if use_bias else None, algo=algo)
         assert_gemm_close(d.float().cpu().numpy(), ref, f"gemm {shape} fmt({fa},{fb}) algo {algo} bias {use_bias}")
-    if algo == 4:
+    if algo >= 4:
         return  # bf16 output only
     # fp32 output
     d32 = ops.gemm_fp8(torch.from_numpy(a8).to(dev), torch.from_numpy(b8).to(dev), _f32(sa, dev), _f32(sb, dev),
@@ -270,12 +274,14 @@ def test_mxfp8_quantize_bitexact(ops, dev, shape, fmt):
 
 
 @pytest.mark.parametrize("shape", [(32, 32, 32), (64, 96, 128), (96, 160, 320), (256, 512, 1024), (256, 256, 256),
-                                   (768, 512, 512), (2048, 2304, 768)])
-@pytest.mark.parametrize("algo", [1, 4])
+                                   (768, 512, 512), (2048, 2304, 768), (768, 576, 512), (384, 1536, 256)])
+@pytest.mark.parametrize("algo", [1, 4, 41, 42, 43])
 def test_gemm_mxfp8_vs_oracle(ops, dev, shape, algo):
     M, N, K = shape
-    if algo == 4 and (M % 256 or N % 256 or K % 256):
-        pytest.skip("persistent MX kernel needs 256-aligned shapes")
+    if algo in (4, 41, 42, 43):
+        bm, bn = {4: (256, 256), 41: (256, 192), 42: (192, 256), 43: (192, 192)}[algo]
+        if M % bm or N % bn or K % 256:
+            pytest.skip("tile shape does not divide the problem")
     g = torch.Generator().manual_seed(M + K)
     a = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, K // 32, generator=g).repeat_interleave(32, 1) * 2)).to(torch.bfloat16)
     b = (torch.randn(N, K, generator=g) * torch.exp(torch.randn(N, K // 32, generator=g).repeat_interleave(32, 1) * 2)).to(torch.bfloat16)

@@ -49,6 +49,19 @@ def main():
                     tf = 2.0 * m * n * k / t / 1e12
                     print(f"gemm {name:4s} {kind:5s} {m:6d}x{n:6d}x{k:6d} algo {algo}: {t*1e6:9.1f} us {tf:8.1f} TFLOP/s "
                           f"({tf/5000*100:5.1f}% of 5 PF)", flush=True)
+    if "tiles" in args.which:
+        for (m, n, k) in ((8192, 3072, 3072), (8192, 3072, 8192), (3072, 8192, 8192), (3072, 3072, 8192), (8192, 3072, 16384),
+                          (8192, 6144, 3072), (6144, 6144, 4096)):
+            a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
+            out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+            for algo in (40, 41, 42, 43, 4):
+                bm, bn = {40: (256, 256), 41: (256, 192), 42: (192, 256), 43: (192, 192), 4: (1, 1)}[algo]
+                if m % bm or n % bn:
+                    continue
+                t = time_fn(lambda: ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=algo), args.iters)
+                tiles = (m // bm) * (n // bn) if algo != 4 else 0
+                print(f"tiles {m}x{n}x{k} algo {algo} ({bm}x{bn}, {tiles} tiles = {tiles/256:.2f} rounds): {t*1e6:8.1f} us "
+                      f"{2.0*m*n*k/t/1e12:7.1f} TFLOP/s", flush=True)
     if "mxgemm" in args.which:
         for name, (M, N, K) in SHAPES_3B.items():
             for kind, (m, n, k) in (("fprop", (M, N, K)), ("dgrad", (M, K, N)), ("wgrad", (N, K, M))):
