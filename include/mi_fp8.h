@@ -139,6 +139,19 @@ int mi_swiglu_cast(const void* h_bf16, void* y_fp8, void* yT_fp8, const float* s
 int mi_dswiglu_cast(const void* h_bf16, const void* dact_bf16, void* y_fp8, void* yT_fp8, const float* scale,
                     float* amax, float* colsum, int64_t rows, int64_t F, int fmt, void* stream);
 
+/*
+ * Optimiser step of the reference loop (train_fp8.py:288-291: clip_grad_norm_(model.parameters(), 1.0) then
+ * AdamW(fused=True).step()), used by llm_fp8_amd.train on the single-GPU path.
+ *   mi_sumsq_bf16: partial[b] = sum of g^2 over block b's grid-stride share, b < n_partials (fixed order: reproducible).
+ *   mi_adamw_bf16: torch.optim.AdamW update on bf16 p / exp_avg / exp_avg_sq with fp32 math; the gradient is
+ *                  multiplied by *grad_scale (device scalar, NULL = 1) -- the clip coefficient, so the gradients are
+ *                  not rescaled in a separate pass.  `step` is the 1-based step count for the bias corrections.
+ */
+int mi_sumsq_bf16(const void* g_bf16, int64_t n, float* partial, int n_partials, void* stream);
+int mi_adamw_bf16(void* p_bf16, const void* g_bf16, void* exp_avg_bf16, void* exp_avg_sq_bf16, int64_t n,
+                  const float* grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  int64_t step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

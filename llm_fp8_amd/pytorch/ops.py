@@ -2,6 +2,7 @@
 function raises if handed a CPU tensor -- there is no PyTorch/CPU fallback for this path."""
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -11,6 +12,20 @@ from .profiler import KernelTimer
 
 E4M3, E5M2 = _lib.MI_FMT_E4M3, _lib.MI_FMT_E5M2
 FP8_MAX = {E4M3: 448.0, E5M2: 57344.0}
+
+
+def default_gemm_algo() -> int:
+    """0 (auto: persistent kernel) on a single GPU.  Under torch.distributed with more than one rank the non-persistent
+    8-phase kernel (3): RCCL's collectives overlap the GEMMs under FSDP / DDP and hold some CUs; a persistent grid with
+    one workgroup per CU and a static tile list would wait for those CUs, while a plain grid is simply scheduled onto the
+    CUs that are free.  Override with LLM_FP8_AMD_GEMM_ALGO."""
+    env = os.environ.get("LLM_FP8_AMD_GEMM_ALGO")
+    if env is not None:
+        return int(env)
+    d = torch.distributed
+    if d.is_available() and d.is_initialized() and d.get_world_size() > 1:
+        return 3
+    return 0
 
 
 def _stream() -> int:
@@ -76,8 +91,12 @@ def scale_update(amax_history: torch.Tensor, scale: torch.Tensor, scale_inv: tor
 def gemm_fp8(a8: torch.Tensor, b8: torch.Tensor, sa_inv: torch.Tensor, sb_inv: torch.Tensor,
              fmt_a: int, fmt_b: int, bias: Optional[torch.Tensor] = None,
              out: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.bfloat16,
-             algo: int = 0) -> torch.Tensor:
+             algo: Optional[int] = None) -> torch.Tensor:
     """K4-K6.  D[M,N] = (A[M,K] . B[N,K]^T) * sa_inv * sb_inv (+ bias)."""
+    if algo is None:
+        algo = default_gemm_algo()
+        if algo == 3 and (a8.shape[0] % 256 or b8.shape[0] % 256 or a8.shape[1] % 128):
+            algo = 0
     _dev(a8, b8, sa_inv, sb_inv, bias, out)
     assert a8.dtype == torch.uint8 and b8.dtype == torch.uint8 and a8.dim() == 2 and b8.dim() == 2
     assert a8.stride(1) == 1 and b8.stride(1) == 1

@@ -112,10 +112,17 @@ def wrap_distributed(model: torch.nn.Module, cfg: TrainingConfig, device) -> tor
 
 
 def create_optimizer(model, cfg: TrainingConfig):
-    """AdamW(fused=True) + linear warmup/decay (train_fp8.py:200-210)."""
+    """AdamW(fused=True) + linear warmup/decay (train_fp8.py:200-210).  On the single-GPU path (bf16 parameters on the
+    device, no FSDP/DDP wrapper) the clip + AdamW pair runs as `ClippedAdamW` (two HIP passes, same update rule)."""
     params = [p for p in model.parameters() if p.requires_grad]
     fused = all(p.is_cuda for p in params)
-    opt = torch.optim.AdamW(params, lr=cfg.learning_rate, fused=fused)
+    wrapped = type(model).__name__ in ("FullyShardedDataParallel", "DistributedDataParallel")
+    if (fused and not wrapped and all(p.dtype == torch.bfloat16 for p in params)
+            and os.environ.get("LLM_FP8_AMD_TORCH_ADAMW") != "1"):
+        from .optim import ClippedAdamW
+        opt = ClippedAdamW(params, lr=cfg.learning_rate, max_grad_norm=cfg.max_grad_norm)
+    else:
+        opt = torch.optim.AdamW(params, lr=cfg.learning_rate, fused=fused)
 
     def lr_lambda(step):
         if step < cfg.num_warmup_steps:
@@ -137,7 +144,9 @@ def train_step(model, batch, optimizer, scheduler, cfg: TrainingConfig):
     outputs = model(**batch)
     loss = outputs.loss
     loss.backward()
-    if hasattr(model, "clip_grad_norm_"):
+    if getattr(optimizer, "max_grad_norm", None) is not None:
+        pass  # ClippedAdamW: the clip coefficient is folded into the update
+    elif hasattr(model, "clip_grad_norm_"):
         model.clip_grad_norm_(cfg.max_grad_norm)  # FSDP
     else:
         torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.max_grad_norm)

@@ -317,3 +317,28 @@ def test_fused_swiglu_mlp_matches_unfused(te, dev):
     sa, sb = a._meta_fwd.state()["scale"], b._meta_fwd.state()["scale"]
     assert torch.equal(sa[:2], sb[:2])  # fc1 input / weight amaxes are identical
     assert torch.allclose(sa[3:5], sb[3:5], rtol=0.02)  # fc2 input amax: fp32 act vs bf16-rounded act
+
+
+def test_clipped_adamw_matches_torch_clip_plus_fused_adamw(dev):
+    """ClippedAdamW == clip_grad_norm_(1.0) + torch.optim.AdamW(fused=True) (train_fp8.py:288-291) up to the bf16 rounding
+    of the rescaled gradient that torch's in-place clip inserts."""
+    from llm_fp8_amd.optim import ClippedAdamW
+    torch.manual_seed(0)
+    shapes = [(1024, 512), (333,), (7, 9), (4096, 1024)]
+    pa = [torch.nn.Parameter(torch.randn(s, device=dev).to(torch.bfloat16)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = ClippedAdamW(pa, lr=1e-2, max_grad_norm=1.0)
+    ob = torch.optim.AdamW(pb, lr=1e-2, fused=True)
+    for step in range(4):
+        for x, y in zip(pa, pb):
+            g = (torch.randn_like(x, dtype=torch.float32) * (0.01 if step == 3 else 1.0)).to(torch.bfloat16)  # last step: norm < 1, no clipping
+            x.grad, y.grad = g.clone(), g.clone()
+        ref_norm = torch.nn.utils.clip_grad_norm_(pb, 1.0)
+        ob.step()
+        oa.step()
+        assert abs(oa.last_grad_norm.item() - ref_norm.item()) <= 2e-3 * ref_norm.item()
+        for x, y in zip(pa, pb):
+            assert torch.isfinite(x).all()
+            d = (x.float() - y.float()).abs()
+            assert (d <= 2.0 ** -7 * y.float().abs() + 1e-4).all(), f"step {step}: max diff {d.max().item()}"
+    assert (torch.cat([(x.float() - y.float()).abs().reshape(-1) for x, y in zip(pa, pb)]) == 0).float().mean() > 0.9
