@@ -594,6 +594,11 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   stage_n<nA1>(rsA, a1_voff, oa_0, buf0 + kOffA1, wave);
   stage_n<2>(rsA, a0_voff, oa_1 + kt_1 * BK, buf1 + kOffA0, wave);
   stage_n<2>(rsB, b0_voff, ob_1 + kt_1 * BK, buf1 + kOffB0, wave);
+  if (ABL == 3) {  // experiment: de-synchronise the CUs' epilogue bursts (odd workgroups start ~K/2 late)
+    if (bid & 1) {
+      for (int i = 0; i < (nk + 5) / 6; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+  }
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
@@ -730,7 +735,11 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
             if (ABL == 1) {
               asm volatile("" ::"v"(o));
             } else {
-              __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)o, rsD, d_voff + ecol * 2, soff, 0);
+              // aux 16 = sc1: write-through, the line is not kept in this XCD's L2.  A tile's 128 KiB of output per CU
+              // (4 MiB per XCD = its whole L2) would otherwise evict the A/B panels the next tile streams:
+              // measured -5..6 % kernel time at K = 2048-4096 (tools/bench_kernels.py --which ksweep, algos 4 vs 17-19).
+              if (ABL == 4) __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)o, rsD, d_voff + ecol * 2, soff, 0);  // plain (ablation)
+              else __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)o, rsD, d_voff + ecol * 2, soff, 16);
               // hipcc (ROCm 7.2) lets the next VALU overwrite the data registers of this 16-byte store (SGPR-offset
               // form) with no wait state: lanes 12-15 of every 16-lane row then stored the NEXT block's unconverted
               // fp32 (seen on MI355X, tools/debug_gemm.py).  Keep the registers live across the required wait states.
@@ -747,7 +756,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
             if (ABL == 1) {
               asm volatile("" ::"v"(o));
             } else {
-              __builtin_amdgcn_raw_buffer_store_b64(o, rsD, d_voff + fq * 8, soff, 0);
+              __builtin_amdgcn_raw_buffer_store_b64(o, rsD, d_voff + fq * 8, soff, 16);
               asm volatile("s_nop 1" ::"v"(o) : "memory");
             }
           }
@@ -842,6 +851,10 @@ static int launch_p8(const uint8_t* a, const uint8_t* b, uint16_t* D, const floa
   }
   if (algo == 15) {
     MI_P8_CFG(false, false, 1)
+  } else if (algo == 16) {
+    MI_P8_CFG(false, false, 3)
+  } else if (algo == 17) {
+    MI_P8_CFG(false, false, 4)
   } else if (mx) {
     if (bias) { MI_P8_CFG(true, true, 0) } else { MI_P8_CFG(true, false, 0) }
   } else {
@@ -867,7 +880,7 @@ static int launch_fmt(const void* A, const void* B, void* D, const float* sa_inv
     int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
     hipLaunchKernelGGL((gemm_256_8ph<FA, FB, OUT>), dim3(tiles_m * tiles_n), dim3(512), 0, st, a, b, D, sa_inv, sb_inv,
                        bp, (int)M, (int)N, (int)K, lda, ldb, ldd, tiles_m, tiles_n);
-  } else if (algo == 4 || algo == 15 || (algo >= 40 && algo <= 43)) {
+  } else if (algo == 4 || (algo >= 15 && algo <= 17) || (algo >= 40 && algo <= 43)) {
     return launch_p8<FA, FB>(a, b, (uint16_t*)D, sa_inv, sb_inv, (const uint8_t*)SA, (const uint8_t*)SB, bp, M, N, K, lda, ldb, ldd,
                              algo, mx, st);
   } else if (algo == 13 && !mx) {
@@ -927,7 +940,7 @@ static int pick_algo(int algo, int64_t M, int64_t N, int64_t K, int64_t lda, int
   const bool p8_ok = (M % 256 == 0 || M % 192 == 0) && (N % 256 == 0 || N % 192 == 0) && M > 0 && N > 0 && K > 0 &&
                      (K % (2 * BK) == 0) && out == 0 && M * lda < (1LL << 31) && N * ldb < (1LL << 31) &&
                      M * ldd * 2 < (1LL << 31);
-  if (algo == 4 || algo == 15 || (algo >= 40 && algo <= 43)) {
+  if (algo == 4 || (algo >= 15 && algo <= 17) || (algo >= 40 && algo <= 43)) {
     if (!p8_ok) {
       set_error("%s: algo %d needs M,N %% 256 (or 192) == 0, K %% 256 == 0, bf16 output, operands < 2 GiB", who, algo);
       return MI_ERR_SHAPE;
