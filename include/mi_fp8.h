@@ -140,6 +140,22 @@ int mi_dswiglu_cast(const void* h_bf16, const void* dact_bf16, void* y_fp8, void
                     float* amax, float* colsum, int64_t rows, int64_t F, int fmt, void* stream);
 
 /*
+ * K9  RMSNorm fused with the FP8 cast of the following GEMM's input  [TE LayerNormLinear / LayerNormMLP with
+ *     normalization="RMSNorm", te_llama.py:45-63: the normalised bf16 activation is never materialised].
+ *   mi_rmsnorm_stats: rstd[r] = rsqrt(mean_c x[r,c]^2 + eps)                                   (fp32, one wave per row)
+ *   mi_norm_cast:     v = (x[r,c] * rstd[r]) * gamma[c] in fp32; y = sat_cast(v * *scale), yT, *amax = max(*amax, max|v|)
+ *   mi_rmsnorm_bwd:   dx = rstd * (dy*gamma - xhat * mean_c(dy*gamma*xhat)) (+ dres), xhat = x*rstd;
+ *                     dgamma_partial[b, c] = sum over block b's rows of dy*xhat (fp32, fixed order; caller adds the blocks).
+ *                     cols % 512 == 0, cols <= 8192.
+ */
+int mi_rmsnorm_stats(const void* x_bf16, float* rstd, int64_t rows, int64_t cols, float eps, void* stream);
+int mi_norm_cast(const void* x_bf16, const float* rstd, const void* gamma_bf16, void* y_fp8, void* yT_fp8,
+                 const float* scale, float* amax, int64_t rows, int64_t cols, int fmt, void* stream);
+int mi_rmsnorm_bwd(const void* dy_bf16, const void* x_bf16, const float* rstd, const void* gamma_bf16,
+                   const void* dres_bf16, void* dx_bf16, float* dgamma_partial, int n_partials, int64_t rows,
+                   int64_t cols, void* stream);
+
+/*
  * Optimiser step of the reference loop (train_fp8.py:288-291: clip_grad_norm_(model.parameters(), 1.0) then
  * AdamW(fused=True).step()), used by llm_fp8_amd.train on the single-GPU path.
  *   mi_sumsq_bf16: partial[b] = sum of g^2 over block b's grid-stride share, b < n_partials (fixed order: reproducible).

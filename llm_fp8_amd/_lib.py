@@ -29,6 +29,9 @@ SIGNATURES = {
     "mi_rope_qkv": [_p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_int, _p],
     "mi_swiglu_cast": [_p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],
     "mi_dswiglu_cast": [_p, _p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],
+    "mi_rmsnorm_stats": [_p, _p, _c_i64, _c_i64, ctypes.c_float, _p],
+    "mi_norm_cast": [_p, _p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],
+    "mi_rmsnorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _c_int, _c_i64, _c_i64, _p],
     "mi_sumsq_bf16": [_p, _c_i64, _p, _c_int, _p],
     "mi_adamw_bf16": [_p, _p, _p, _p, _c_i64, _p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                       ctypes.c_float, _c_i64, _p],

@@ -5,6 +5,8 @@
 //                       kernel at this point of the reference path, te_llama.py:77).
 //   mi_swiglu_cast      K10 fwd: act = silu(h[:, :F]) * h[:, F:] in fp32 -> FP8 (+ transposed copy) + amax,
 //                       without materialising the bf16 activation (te_llama.py:62 activation="swiglu").
+//   mi_rmsnorm_stats / mi_norm_cast / mi_rmsnorm_bwd   K9: RMSNorm fused with the FP8 cast of the GEMM input
+//                       (the normalised bf16 activation is never materialised) and its backward.
 //   mi_dswiglu_cast     K10 bwd: dh = [dact * dsilu(g) * u | dact * silu(g)] in fp32 -> FP8 (+T) + amax,
 //                       plus deterministic per-row-block column sums for the fc1 bias gradient.
 #include "mi_common.h"
@@ -201,6 +203,178 @@ static int launch_swiglu(const void* h, const void* d, void* y, void* yT, const 
   return MI_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ K9: RMSNorm -> FP8
+// rstd[r] = rsqrt(mean_c x[r,c]^2 + eps).  One wave per row, 16-B loads, fp32 accumulation in a fixed order.
+__global__ __launch_bounds__(256) void rmsnorm_stats_kernel(const uint16_t* __restrict__ x, float* __restrict__ rstd, int rows,
+                                                            int cols, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const uint16_t* xr = x + (int64_t)row * cols;
+  float acc = 0.0f;
+  for (int c = lane * 8; c < cols; c += 512) {
+    const v4i v = *reinterpret_cast<const v4i*>(xr + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32 w = (u32)v[j];
+      const float a = __uint_as_float(w << 16), b = __uint_as_float(w & 0xFFFF0000u);
+      acc += a * a + b * b;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) rstd[row] = rsqrtf(acc / (float)cols + eps);
+}
+
+// y = (x * rstd[row]) * gamma[col] in fp32 -> FP8 (+ transposed copy) + amax: the normalised activation is never
+// written in bf16 (TE LayerNormLinear / LayerNormMLP do the same on the reference path, te_llama.py:45-63).
+template <int FMT, bool WRITE_Y, bool WRITE_T>
+__global__ __launch_bounds__(256) void norm_cast_kernel(const uint16_t* __restrict__ x, const float* __restrict__ rstd,
+                                                        const uint16_t* __restrict__ gamma, uint8_t* __restrict__ y,
+                                                        uint8_t* __restrict__ yT, const float* __restrict__ scale_p,
+                                                        float* amax_out, int rows, int cols, int tiles_c) {
+  __shared__ float s_amax[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile_r = blockIdx.x / tiles_c, tile_c = blockIdx.x % tiles_c;
+  const int r0 = tile_r * 128 + (wave >> 1) * 64 + (lane >> 3) * 8;
+  const int c0 = tile_c * 128 + (wave & 1) * 64 + (lane & 7) * 8;
+  const float scale = *scale_p;
+  float amax = 0.0f;
+  if ((r0 < rows) && (c0 < cols)) {
+    float g[8];
+    {
+      const v4i gv = *reinterpret_cast<const v4i*>(gamma + c0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        g[2 * j] = __uint_as_float((u32)gv[j] << 16);
+        g[2 * j + 1] = __uint_as_float((u32)gv[j] & 0xFFFF0000u);
+      }
+    }
+    u32 lo[8], hi[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const v4i raw = *reinterpret_cast<const v4i*>(x + (int64_t)(r0 + i) * cols + c0);
+      const float rs = rstd[r0 + i];
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32 w = (u32)raw[j];
+        f[2 * j] = (__uint_as_float(w << 16) * rs) * g[2 * j];
+        f[2 * j + 1] = (__uint_as_float(w & 0xFFFF0000u) * rs) * g[2 * j + 1];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, (f[j] != f[j]) ? 0.0f : fabsf(f[j]));
+      lo[i] = cvt4_fp8<FMT>(f[0] * scale, f[1] * scale, f[2] * scale, f[3] * scale);
+      hi[i] = cvt4_fp8<FMT>(f[4] * scale, f[5] * scale, f[6] * scale, f[7] * scale);
+    }
+    if (WRITE_Y) {
+      uint8_t* dst = y + (int64_t)r0 * cols + c0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<uint2*>(dst + (int64_t)i * cols) = make_uint2(lo[i], hi[i]);
+    }
+    if (WRITE_T) {
+      u32 a[4], b[4], c[4], d[4];
+      transpose4x4(lo[0], lo[1], lo[2], lo[3], a[0], a[1], a[2], a[3]);
+      transpose4x4(lo[4], lo[5], lo[6], lo[7], b[0], b[1], b[2], b[3]);
+      transpose4x4(hi[0], hi[1], hi[2], hi[3], c[0], c[1], c[2], c[3]);
+      transpose4x4(hi[4], hi[5], hi[6], hi[7], d[0], d[1], d[2], d[3]);
+      uint8_t* dst = yT + (int64_t)c0 * rows + r0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<uint2*>(dst + (int64_t)j * rows) = make_uint2(a[j], b[j]);
+        *reinterpret_cast<uint2*>(dst + (int64_t)(j + 4) * rows) = make_uint2(c[j], d[j]);
+      }
+    }
+  }
+  if (amax_out != nullptr) {
+    amax = wave_max(amax);
+    if (lane == 0) s_amax[wave] = amax;
+    __syncthreads();
+    if (tid == 0) {
+      float m = fmaxf(fmaxf(s_amax[0], s_amax[1]), fmaxf(s_amax[2], s_amax[3]));
+      if (m > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(amax_out), __float_as_uint(m));
+    }
+  }
+}
+
+// RMSNorm backward.  dy = grad w.r.t. the normalised output (the dgrad GEMM's bf16 result), xhat = x * rstd:
+//   dx[r,c]  = rstd[r] * (dy*g - xhat * mean_c(dy*g*xhat))          (+ dres[r,c] if a residual gradient is given)
+//   dgp[b,c] = sum over block b's rows of dy * xhat                  (fp32 partials, fixed order; caller adds the blocks)
+// One wave per row per pass (the row lives in registers: cols <= 8192), 4 waves per block, ROWS_PER_WAVE rows per wave.
+constexpr int kNormMaxVec = 16;  // 16 x 8 x 64 = 8192 columns
+template <int NVEC>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
+                                                          const float* __restrict__ rstd, const uint16_t* __restrict__ gamma,
+                                                          const uint16_t* __restrict__ dres, uint16_t* __restrict__ dx,
+                                                          float* __restrict__ dgp, int rows, int rows_per_block) {
+  extern __shared__ float s_dg[];  // [4][cols]
+  constexpr int cols = NVEC * 512;  // 512 columns per wave-wide vector step
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v4i gq[NVEC];          // gamma, packed bf16
+  float dgacc[NVEC][8];  // this wave's share of dgamma
+#pragma unroll
+  for (int v = 0; v < NVEC; ++v) {
+    gq[v] = *reinterpret_cast<const v4i*>(gamma + v * 512 + lane * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dgacc[v][j] = 0.0f;
+  }
+  const int row_begin = blockIdx.x * rows_per_block;
+  const int row_end = min(rows, row_begin + rows_per_block);
+  for (int row = row_begin + wave; row < row_end; row += 4) {
+    const float rs = rstd[row];
+    v4i dq[NVEC], xq[NVEC];
+    float dot = 0.0f;
+#pragma unroll
+    for (int v = 0; v < NVEC; ++v) {
+      const int64_t off = (int64_t)row * cols + v * 512 + lane * 8;
+      dq[v] = *reinterpret_cast<const v4i*>(dy + off);
+      xq[v] = *reinterpret_cast<const v4i*>(x + off);
+    }
+#pragma unroll
+    for (int v = 0; v < NVEC; ++v)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d0 = __uint_as_float((u32)dq[v][j] << 16), d1 = __uint_as_float((u32)dq[v][j] & 0xFFFF0000u);
+        const float x0 = __uint_as_float((u32)xq[v][j] << 16) * rs, x1 = __uint_as_float((u32)xq[v][j] & 0xFFFF0000u) * rs;
+        const float g0 = __uint_as_float((u32)gq[v][j] << 16), g1 = __uint_as_float((u32)gq[v][j] & 0xFFFF0000u);
+        dgacc[v][2 * j] += d0 * x0;
+        dgacc[v][2 * j + 1] += d1 * x1;
+        dot += (d0 * g0) * x0 + (d1 * g1) * x1;
+      }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) dot += __shfl_xor(dot, o);
+    const float c = dot / (float)cols;
+#pragma unroll
+    for (int v = 0; v < NVEC; ++v) {
+      const int64_t off = (int64_t)row * cols + v * 512 + lane * 8;
+      v4i rv = {0, 0, 0, 0};
+      if (dres) rv = *reinterpret_cast<const v4i*>(dres + off);
+      v4i ov;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d0 = __uint_as_float((u32)dq[v][j] << 16), d1 = __uint_as_float((u32)dq[v][j] & 0xFFFF0000u);
+        const float x0 = __uint_as_float((u32)xq[v][j] << 16) * rs, x1 = __uint_as_float((u32)xq[v][j] & 0xFFFF0000u) * rs;
+        const float g0 = __uint_as_float((u32)gq[v][j] << 16), g1 = __uint_as_float((u32)gq[v][j] & 0xFFFF0000u);
+        float o0 = rs * (d0 * g0 - x0 * c), o1 = rs * (d1 * g1 - x1 * c);
+        if (dres) {
+          o0 += __uint_as_float((u32)rv[j] << 16);
+          o1 += __uint_as_float((u32)rv[j] & 0xFFFF0000u);
+        }
+        ov[j] = (int)pack_bf16x2(o0, o1);
+      }
+      *reinterpret_cast<v4i*>(dx + off) = ov;
+    }
+  }
+  // block-level dgamma partial: 4 waves -> LDS -> one row of dgp (fixed order)
+#pragma unroll
+  for (int v = 0; v < NVEC; ++v)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s_dg[wave * cols + v * 512 + lane * 8 + j] = dgacc[v][j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < cols; c += 256)
+    dgp[(int64_t)blockIdx.x * cols + c] = (s_dg[c] + s_dg[cols + c]) + (s_dg[2 * cols + c] + s_dg[3 * cols + c]);
+}
+
 }  // namespace mi
 
 extern "C" int mi_rope_qkv(void* fused_bf16, void* q_bf16, void* k_bf16, void* v_bf16, const float* cos_tab,
@@ -260,4 +434,71 @@ extern "C" int mi_dswiglu_cast(const void* h_bf16, const void* dact_bf16, void* 
   if (fmt == MI_FMT_E4M3)
     return mi::launch_swiglu<MI_FMT_E4M3, 1>(h_bf16, dact_bf16, y_fp8, yT_fp8, scale, amax, colsum, rows, F, st);
   return mi::launch_swiglu<MI_FMT_E5M2, 1>(h_bf16, dact_bf16, y_fp8, yT_fp8, scale, amax, colsum, rows, F, st);
+}
+
+extern "C" int mi_rmsnorm_stats(const void* x_bf16, float* rstd, int64_t rows, int64_t cols, float eps, void* stream) {
+  MI_CHECK_ARG(x_bf16 && rstd, "mi_rmsnorm_stats: null pointer");
+  MI_CHECK_ARG(rows >= 0 && cols > 0 && cols % 8 == 0 && rows < (1LL << 31) && cols < (1LL << 31), "mi_rmsnorm_stats: bad shape");
+  MI_CHECK_ARG(((uintptr_t)x_bf16 % 16) == 0, "mi_rmsnorm_stats: x must be 16-byte aligned");
+  if (rows == 0) return MI_OK;
+  hipLaunchKernelGGL(mi::rmsnorm_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)x_bf16, rstd, (int)rows, (int)cols, eps);
+  MI_CHECK_LAUNCH("mi_rmsnorm_stats launch");
+  return MI_OK;
+}
+
+extern "C" int mi_norm_cast(const void* x_bf16, const float* rstd, const void* gamma_bf16, void* y_fp8, void* yT_fp8,
+                            const float* scale, float* amax, int64_t rows, int64_t cols, int fmt, void* stream) {
+  MI_CHECK_ARG(x_bf16 && rstd && gamma_bf16 && scale, "mi_norm_cast: null input");
+  MI_CHECK_ARG(y_fp8 || yT_fp8, "mi_norm_cast: at least one of y, yT must be non-null");
+  MI_CHECK_ARG(rows >= 0 && cols >= 0 && rows % 8 == 0 && cols % 8 == 0, "mi_norm_cast: rows and cols must be multiples of 8");
+  MI_CHECK_ARG(rows < (1LL << 31) && cols < (1LL << 31), "mi_norm_cast: shape too large");
+  MI_CHECK_ARG(((uintptr_t)x_bf16 % 16) == 0 && ((uintptr_t)gamma_bf16 % 16) == 0 && ((uintptr_t)y_fp8 % 8) == 0 &&
+                   ((uintptr_t)yT_fp8 % 8) == 0, "mi_norm_cast: misaligned pointer");
+  MI_CHECK_ARG(fmt == MI_FMT_E4M3 || fmt == MI_FMT_E5M2, "mi_norm_cast: bad fmt %d", fmt);
+  if (rows == 0 || cols == 0) return MI_OK;
+  const int tiles_r = (int)((rows + 127) / 128), tiles_c = (int)((cols + 127) / 128);
+  dim3 grid((unsigned)(tiles_r * tiles_c)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const uint16_t *xp = (const uint16_t*)x_bf16, *gp = (const uint16_t*)gamma_bf16;
+  uint8_t *yp = (uint8_t*)y_fp8, *tp = (uint8_t*)yT_fp8;
+#define MI_NC(FMTv)                                                                                                        \
+  if (y_fp8 && yT_fp8)                                                                                                     \
+    hipLaunchKernelGGL((mi::norm_cast_kernel<FMTv, true, true>), grid, block, 0, st, xp, rstd, gp, yp, tp, scale, amax, (int)rows, (int)cols, tiles_c); \
+  else if (y_fp8)                                                                                                          \
+    hipLaunchKernelGGL((mi::norm_cast_kernel<FMTv, true, false>), grid, block, 0, st, xp, rstd, gp, yp, tp, scale, amax, (int)rows, (int)cols, tiles_c); \
+  else                                                                                                                     \
+    hipLaunchKernelGGL((mi::norm_cast_kernel<FMTv, false, true>), grid, block, 0, st, xp, rstd, gp, yp, tp, scale, amax, (int)rows, (int)cols, tiles_c);
+  if (fmt == MI_FMT_E4M3) { MI_NC(MI_FMT_E4M3) } else { MI_NC(MI_FMT_E5M2) }
+#undef MI_NC
+  MI_CHECK_LAUNCH("mi_norm_cast launch");
+  return MI_OK;
+}
+
+extern "C" int mi_rmsnorm_bwd(const void* dy_bf16, const void* x_bf16, const float* rstd, const void* gamma_bf16,
+                              const void* dres_bf16, void* dx_bf16, float* dgamma_partial, int n_partials, int64_t rows,
+                              int64_t cols, void* stream) {
+  MI_CHECK_ARG(dy_bf16 && x_bf16 && rstd && gamma_bf16 && dx_bf16 && dgamma_partial, "mi_rmsnorm_bwd: null pointer");
+  MI_CHECK_ARG(rows >= 0 && cols > 0 && cols % 512 == 0 && cols <= 512 * mi::kNormMaxVec, "mi_rmsnorm_bwd: cols must be a multiple of 512, at most %d", 512 * mi::kNormMaxVec);
+  MI_CHECK_ARG(n_partials >= 1 && rows < (1LL << 31), "mi_rmsnorm_bwd: bad sizes");
+  MI_CHECK_ARG(((uintptr_t)dy_bf16 % 16) == 0 && ((uintptr_t)x_bf16 % 16) == 0 && ((uintptr_t)gamma_bf16 % 16) == 0 &&
+                   ((uintptr_t)dres_bf16 % 16) == 0 && ((uintptr_t)dx_bf16 % 16) == 0, "mi_rmsnorm_bwd: misaligned pointer");
+  const int rows_per_block = (int)((rows + n_partials - 1) / n_partials);
+  const int rpb = rows_per_block < 1 ? 1 : rows_per_block;
+  const size_t shm = (size_t)(4 * cols * sizeof(float));
+#define MI_RB(NV)                                                                                                         \
+  case NV:                                                                                                                \
+    hipLaunchKernelGGL(mi::rmsnorm_bwd_kernel<NV>, dim3(n_partials), dim3(256), shm, (hipStream_t)stream,                 \
+                       (const uint16_t*)dy_bf16, (const uint16_t*)x_bf16, rstd, (const uint16_t*)gamma_bf16,              \
+                       (const uint16_t*)dres_bf16, (uint16_t*)dx_bf16, dgamma_partial, (int)rows, rpb);                   \
+    break;
+  switch ((int)(cols / 512)) {
+    MI_RB(1) MI_RB(2) MI_RB(3) MI_RB(4) MI_RB(5) MI_RB(6) MI_RB(7) MI_RB(8) MI_RB(10) MI_RB(12) MI_RB(14) MI_RB(16)
+    default:
+      mi::set_error("mi_rmsnorm_bwd: unsupported width %lld (cols/512 must be 1-8, 10, 12, 14 or 16)", (long long)cols);
+      return MI_ERR_SHAPE;
+  }
+#undef MI_RB
+  MI_CHECK_LAUNCH("mi_rmsnorm_bwd launch");
+  return MI_OK;
 }

@@ -36,9 +36,10 @@ def _as_bf16_2d(t: torch.Tensor) -> torch.Tensor:
 
 class _GemmSpec:
     """Everything non-tensor a GEMM site needs: recipe, meta windows, slot base, update trigger."""
-    __slots__ = ("recipe", "meta_fwd", "meta_bwd", "g", "fmt_fwd", "fmt_bwd", "trigger_bwd_update", "training")
+    __slots__ = ("recipe", "meta_fwd", "meta_bwd", "g", "fmt_fwd", "fmt_bwd", "trigger_bwd_update", "training", "eps")
 
-    def __init__(self, recipe, meta_fwd, meta_bwd, g, trigger_bwd_update, training):
+    def __init__(self, recipe, meta_fwd, meta_bwd, g, trigger_bwd_update, training, eps=1e-5):
+        self.eps = eps
         self.recipe, self.meta_fwd, self.meta_bwd, self.g = recipe, meta_fwd, meta_bwd, g
         self.fmt_fwd, self.fmt_bwd = fmt_codes(recipe.fp8_format)
         self.trigger_bwd_update = trigger_bwd_update
@@ -49,7 +50,9 @@ class _FP8LinearFn(torch.autograd.Function):
     """y[M, sum N_i] = x[M,K] . cat(W_i)[N,K]^T (+ bias), FP8 operands, bf16 result."""
 
     @staticmethod
-    def forward(ctx, x: torch.Tensor, bias: Optional[torch.Tensor], spec: _GemmSpec, *weights: torch.Tensor):
+    def forward(ctx, x: torch.Tensor, bias: Optional[torch.Tensor], spec: _GemmSpec, ln_w: Optional[torch.Tensor],
+                *weights: torch.Tensor):
+        """`ln_w` (with spec.eps): K9 -- x is the UN-normalised input and RMSNorm is fused into its FP8 cast."""
         x2 = _as_bf16_2d(x)
         M, K = x2.shape
         if M % 8 or K % 16:
@@ -58,10 +61,12 @@ class _FP8LinearFn(torch.autograd.Function):
         N = sum(ns)
         dev = x2.device
         # (forward runs in no-grad mode; needs_input_grad is all-False when grad was disabled at apply time)
-        need_dgrad = bool(ctx.needs_input_grad[0])
-        need_wgrad = any(ctx.needs_input_grad[3:])
+        need_dgrad = bool(ctx.needs_input_grad[0]) or bool(ctx.needs_input_grad[3])
+        need_wgrad = any(ctx.needs_input_grad[4:])
         bias_bf16 = None if bias is None else bias.to(torch.bfloat16).contiguous()
+        ctx.norm = None
         if spec.recipe.mxfp8():
+            assert ln_w is None, "fused RMSNorm is only wired for delayed scaling"
             wcat = weights[0] if len(weights) == 1 else torch.cat(list(weights), 0)
             wcat = wcat if wcat.dtype == torch.bfloat16 else wcat.to(torch.bfloat16)
             x8, xs, xt8, xts = ops.mxfp8_quantize(x2, spec.fmt_fwd, rowwise=True, colwise=need_wgrad)
@@ -70,7 +75,14 @@ class _FP8LinearFn(torch.autograd.Function):
             ctx.saved_fp8 = (xt8, xts, wt8, wts, None)
         else:
             mf, g = spec.meta_fwd, spec.g
-            x8, x8t = ops.cast_amax(x2, mf.scale(3 * g), mf.amax(3 * g), spec.fmt_fwd, want_t=need_wgrad)
+            if ln_w is not None:
+                gam = (ln_w if ln_w.dtype == torch.bfloat16 else ln_w.to(torch.bfloat16)).contiguous()
+                rstd = ops.rmsnorm_stats(x2, spec.eps)
+                x8, x8t = ops.norm_cast(x2, rstd, gam, mf.scale(3 * g), mf.amax(3 * g), spec.fmt_fwd, want_t=need_wgrad)
+                if need_dgrad:
+                    ctx.norm = (x2, rstd, gam, ln_w.dtype)
+            else:
+                x8, x8t = ops.cast_amax(x2, mf.scale(3 * g), mf.amax(3 * g), spec.fmt_fwd, want_t=need_wgrad)
             w8 = torch.empty((N, K), dtype=torch.uint8, device=dev)
             w8t = torch.empty((K, N), dtype=torch.uint8, device=dev) if need_dgrad else None
             r = 0
@@ -116,6 +128,12 @@ class _FP8LinearFn(torch.autograd.Function):
         db = None
         if ctx.has_bias:
             db = g2.sum(0, dtype=torch.float32).to(ctx.bias_dtype)
+        dln = None
+        if ctx.norm is not None and dx is not None:
+            xin, rstd, gam, ln_dtype = ctx.norm
+            ctx.norm = None
+            dx, dgam = ops.rmsnorm_bwd(dx, xin, rstd, gam)
+            dln = dgam.to(ln_dtype)
         if spec.trigger_bwd_update:
             # this GEMM belongs to the first FP8 module of the outermost autocast: its backward is the last
             FP8GlobalStateManager.reduce_and_update_fp8_tensors(forward=False)
@@ -125,7 +143,7 @@ class _FP8LinearFn(torch.autograd.Function):
         if dw is not None:
             parts = torch.split(dw, ctx.ns, dim=0)
             dws = [p if p.dtype == dt else p.to(dt) for p, dt in zip(parts, ctx.w_dtypes)]
-        return (dx, db, None, *dws)
+        return (dx, db, None, dln, *dws)
 
 
 class _FP8SwiGLUMLPFn(torch.autograd.Function):
@@ -134,16 +152,24 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
     fc1's grad_output and returns the fc1 bias gradient from the same pass."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, spec: _GemmSpec):
+    def forward(ctx, x, w1, b1, w2, b2, spec: _GemmSpec, ln_w=None):
         x2 = _as_bf16_2d(x)
         M, K = x2.shape
         if M % 8 or K % 16:
             raise RuntimeError(f"FP8 LayerNormMLP needs tokens % 8 == 0 and hidden % 16 == 0, got {M} x {K}")
         mf, fmt = spec.meta_fwd, spec.fmt_fwd
-        need_dgrad = bool(ctx.needs_input_grad[0])
+        need_dgrad = bool(ctx.needs_input_grad[0]) or bool(ctx.needs_input_grad[6])
         need_w = bool(ctx.needs_input_grad[1]) or bool(ctx.needs_input_grad[3])
         bwd = need_dgrad or need_w
-        x8, x8t = ops.cast_amax(x2, mf.scale(0), mf.amax(0), fmt, want_t=need_w)
+        ctx.norm = None
+        if ln_w is not None:  # K9: x is the un-normalised input
+            gam = (ln_w if ln_w.dtype == torch.bfloat16 else ln_w.to(torch.bfloat16)).contiguous()
+            rstd = ops.rmsnorm_stats(x2, spec.eps)
+            x8, x8t = ops.norm_cast(x2, rstd, gam, mf.scale(0), mf.amax(0), fmt, want_t=need_w)
+            if need_dgrad:
+                ctx.norm = (x2, rstd, gam, ln_w.dtype)
+        else:
+            x8, x8t = ops.cast_amax(x2, mf.scale(0), mf.amax(0), fmt, want_t=need_w)
         w1b = (w1 if w1.dtype == torch.bfloat16 else w1.to(torch.bfloat16)).contiguous()
         w1_8, w1_8t = ops.cast_amax(w1b, mf.scale(1), mf.amax(1), fmt, want_t=bwd)
         h = ops.gemm_fp8(x8, w1_8, mf.scale_inv(0), mf.scale_inv(1), fmt, fmt,
@@ -178,6 +204,12 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
         db1 = colsum.sum(0).to(ctx.dtypes[1]) if want_b1 else None
         dx = ops.gemm_fp8(dh8, w1_8t, mb.scale_inv(0), sinv[1:2], fmt_b, fmt_f) if ctx.need_dgrad else None
         dw1 = ops.gemm_fp8(dh8t, x8t, mb.scale_inv(0), sinv[0:1], fmt_b, fmt_f) if ctx.need_w else None
+        dln = None
+        if ctx.norm is not None and dx is not None:
+            xin, rstd, gam, ln_dtype = ctx.norm
+            ctx.norm = None
+            dx, dgam = ops.rmsnorm_bwd(dx, xin, rstd, gam)
+            dln = dgam.to(ln_dtype)
         if spec.trigger_bwd_update:
             FP8GlobalStateManager.reduce_and_update_fp8_tensors(forward=False)
         if dx is not None:
@@ -186,7 +218,7 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
             dw1 = dw1.to(ctx.dtypes[0])
         if dw2 is not None and dw2.dtype != ctx.dtypes[2]:
             dw2 = dw2.to(ctx.dtypes[2])
-        return dx, dw1, db1, dw2, db2, None
+        return dx, dw1, db1, dw2, db2, None, dln
 
 
 class _FP8Module(torch.nn.Module):
@@ -306,7 +338,7 @@ class Linear(_FP8Module):
             return F.linear(inp, self.weight.to(inp.dtype), None if self.bias is None else self.bias.to(inp.dtype))
         recipe, mf, mb, first = st
         spec = _GemmSpec(recipe, mf, mb, 0, first, self.training)
-        return _FP8LinearFn.apply(inp, self.bias, spec, self.weight)
+        return _FP8LinearFn.apply(inp, self.bias, spec, None, self.weight)
 
     def extra_repr(self):
         return f"in_features={self.in_features}, out_features={self.out_features}, bias={self.use_bias}"
@@ -369,15 +401,26 @@ class LayerNormLinear(_FP8Module):
 
     def forward(self, inp: torch.Tensor, is_first_microbatch=None):
         st = self._prepare(inp.device)
-        ln = self._norm(inp)
         ws, b = self._weights(), self._bias()
+        if st is not None and _can_fuse_norm(self, st[0], inp) and not self.return_layernorm_output:
+            recipe, mf, mb, first = st
+            return _FP8LinearFn.apply(inp, b, _GemmSpec(recipe, mf, mb, 0, first, self.training, self.eps),
+                                      self.layer_norm_weight, *ws)
+        ln = self._norm(inp)
         if st is None:
             w = ws[0] if len(ws) == 1 else torch.cat(ws, 0)
             out = F.linear(ln, w.to(ln.dtype), None if b is None else b.to(ln.dtype))
         else:
             recipe, mf, mb, first = st
-            out = _FP8LinearFn.apply(ln, b, _GemmSpec(recipe, mf, mb, 0, first, self.training), *ws)
+            out = _FP8LinearFn.apply(ln, b, _GemmSpec(recipe, mf, mb, 0, first, self.training), None, *ws)
         return (out, ln) if self.return_layernorm_output else out
+
+
+def _can_fuse_norm(mod, recipe, inp) -> bool:
+    """K9 applies to RMSNorm under delayed scaling; the backward kernel keeps a whole row per wave (cols % 512, <= 8192)."""
+    h = inp.shape[-1]
+    return (getattr(mod, "fused_norm", True) and mod.normalization == "RMSNorm" and not mod.zero_centered_gamma
+            and recipe.delayed() and h % 512 == 0 and h // 512 in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16))
 
 
 def _swiglu(a: torch.Tensor) -> torch.Tensor:
@@ -426,6 +469,10 @@ class LayerNormMLP(_FP8Module):
 
     def forward(self, inp: torch.Tensor, is_first_microbatch=None) -> torch.Tensor:
         st = self._prepare(inp.device)
+        if (st is not None and self.activation == "swiglu" and self.fused_swiglu and _can_fuse_norm(self, st[0], inp)):
+            recipe, mf, mb, first = st  # K9 + K10: norm -> cast, fc1, SwiGLU -> cast, fc2 in one autograd node
+            return _FP8SwiGLUMLPFn.apply(inp, self.fc1_weight, self.fc1_bias, self.fc2_weight, self.fc2_bias,
+                                         _GemmSpec(recipe, mf, mb, 0, first, self.training, self.eps), self.layer_norm_weight)
         ln = self._norm(inp)
         if st is None:
             h = F.linear(ln, self.fc1_weight.to(ln.dtype), None if self.fc1_bias is None else self.fc1_bias.to(ln.dtype))
@@ -436,6 +483,6 @@ class LayerNormMLP(_FP8Module):
             return _FP8SwiGLUMLPFn.apply(ln, self.fc1_weight, self.fc1_bias, self.fc2_weight, self.fc2_bias,
                                          _GemmSpec(recipe, mf, mb, 0, first, self.training))
         # fc1's backward is the last FP8 op of this module's backward -> it carries the update trigger
-        h = _FP8LinearFn.apply(ln, self.fc1_bias, _GemmSpec(recipe, mf, mb, 0, first, self.training), self.fc1_weight)
+        h = _FP8LinearFn.apply(ln, self.fc1_bias, _GemmSpec(recipe, mf, mb, 0, first, self.training), None, self.fc1_weight)
         a = self.act_fn(h)
-        return _FP8LinearFn.apply(a, self.fc2_bias, _GemmSpec(recipe, mf, mb, 1, False, self.training), self.fc2_weight)
+        return _FP8LinearFn.apply(a, self.fc2_bias, _GemmSpec(recipe, mf, mb, 1, False, self.training), None, self.fc2_weight)

@@ -236,3 +236,47 @@ def dswiglu_cast(h: torch.Tensor, dact: torch.Tensor, scale: torch.Tensor, amax:
             rc = _lib.load().mi_dswiglu_cast(*args)
     _lib.check(rc, "mi_dswiglu_cast")
     return y, yT, cs
+
+
+def rmsnorm_stats(x: torch.Tensor, eps: float) -> torch.Tensor:
+    """K9: rstd[r] = rsqrt(mean(x[r]^2) + eps), fp32 [R]."""
+    _dev(x)
+    assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.is_contiguous()
+    R, C = x.shape
+    rstd = torch.empty(R, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().mi_rmsnorm_stats(x.data_ptr(), rstd.data_ptr(), R, C, float(eps), _stream()), "mi_rmsnorm_stats")
+    return rstd
+
+
+def norm_cast(x: torch.Tensor, rstd: torch.Tensor, gamma: torch.Tensor, scale: torch.Tensor, amax: Optional[torch.Tensor],
+              fmt: int, want_y: bool = True, want_t: bool = True):
+    """K9: (x * rstd[:, None]) * gamma in fp32 -> (y8 [R, C], y8T [C, R]) + amax; no bf16 normalised tensor is written."""
+    _dev(x, rstd, gamma, scale, amax)
+    assert x.dtype == torch.bfloat16 and gamma.dtype == torch.bfloat16 and x.is_contiguous() and gamma.is_contiguous()
+    R, C = x.shape
+    y = torch.empty((R, C), dtype=torch.uint8, device=x.device) if want_y else None
+    yT = torch.empty((C, R), dtype=torch.uint8, device=x.device) if want_t else None
+    args = (x.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), _ptr(y), _ptr(yT), scale.data_ptr(), _ptr(amax), R, C, fmt, _stream())
+    t = KernelTimer.active
+    if t is None:
+        rc = _lib.load().mi_norm_cast(*args)
+    else:
+        with t.span("norm_cast", f"{R}x{C}", float(R * C), float(R * C * (2 + int(want_y) + int(want_t)))):
+            rc = _lib.load().mi_norm_cast(*args)
+    _lib.check(rc, "mi_norm_cast")
+    return y, yT
+
+
+def rmsnorm_bwd(dy: torch.Tensor, x: torch.Tensor, rstd: torch.Tensor, gamma: torch.Tensor,
+                dres: Optional[torch.Tensor] = None, n_partials: int = 512):
+    """K9 backward: (dx bf16 [R, C], dgamma fp32 [C]).  dgamma is the fixed-order sum of per-block partials."""
+    _dev(dy, x, rstd, gamma, dres)
+    assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous()
+    R, C = x.shape
+    n_partials = max(1, min(n_partials, (R + 3) // 4))
+    dx = torch.empty_like(x)
+    part = torch.empty((n_partials, C), dtype=torch.float32, device=x.device)
+    rc = _lib.load().mi_rmsnorm_bwd(dy.data_ptr(), x.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), _ptr(dres), dx.data_ptr(),
+                                    part.data_ptr(), n_partials, R, C, _stream())
+    _lib.check(rc, "mi_rmsnorm_bwd")
+    return dx, part.sum(0)

@@ -379,3 +379,24 @@ def rope_f32(x_bits: np.ndarray, pos: np.ndarray, head_dim: int, base: float = 1
     x1, x2 = xh[..., :half], xh[..., half:]
     out = np.concatenate([x1 * c[:, None, :] - x2 * s[:, None, :], x2 * c[:, None, :] + x1 * s[:, None, :]], axis=-1)
     return f32_to_bf16_bits(out.reshape(t, w).astype(np.float32))
+
+
+def rmsnorm_f32(x_bits: np.ndarray, gamma_bits: np.ndarray, eps: float):
+    """(y float32 [R, C], rstd float32 [R]): y = x * rsqrt(mean(x^2) + eps) * gamma, float64 math (K9)."""
+    x = bf16_bits_to_f32(x_bits).astype(np.float64)
+    g = bf16_bits_to_f32(gamma_bits).astype(np.float64)
+    rstd = 1.0 / np.sqrt((x * x).mean(axis=1) + eps)
+    return (x * rstd[:, None] * g[None, :]).astype(np.float32), rstd.astype(np.float32)
+
+
+def rmsnorm_bwd_f32(dy_bits: np.ndarray, x_bits: np.ndarray, gamma_bits: np.ndarray, eps: float):
+    """(dx float32, dgamma float32) of y = x * rstd * gamma."""
+    dy = bf16_bits_to_f32(dy_bits).astype(np.float64)
+    x = bf16_bits_to_f32(x_bits).astype(np.float64)
+    g = bf16_bits_to_f32(gamma_bits).astype(np.float64)
+    rstd = 1.0 / np.sqrt((x * x).mean(axis=1) + eps)
+    xh = x * rstd[:, None]
+    wdy = dy * g[None, :]
+    c = (wdy * xh).mean(axis=1)
+    dx = rstd[:, None] * (wdy - xh * c[:, None])
+    return dx.astype(np.float32), (dy * xh).sum(axis=0).astype(np.float32)

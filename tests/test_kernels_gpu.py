@@ -378,3 +378,30 @@ def test_rope_qkv_split_and_merge_vs_oracle(ops, dev, B, S, nq, nkv, D):
     assert np.all(np.abs(bf - xf) <= 2.0 ** -6 * np.abs(xf) + 2.0 ** -7 * np.abs(xf).max())
     dq_ref = O.rope_f32(bf16_bits(q), pos, D, conj=True)
     assert np.all(np.abs(back[:, :nq * D].float().cpu().numpy() - O.bf16_bits_to_f32(dq_ref)) <= 2.0 ** -7 * np.abs(O.bf16_bits_to_f32(dq_ref)) + 1e-5 * np.abs(xf).max())
+
+
+# ----------------------------------------------------------------------------------------- K9 RMSNorm -> FP8
+@pytest.mark.parametrize("shape", [(8, 512), (136, 1024), (1024, 3072), (64, 4096)])
+def test_rmsnorm_cast_and_backward_vs_oracle(ops, dev, shape):
+    R, C = shape
+    g = torch.Generator().manual_seed(R + C)
+    x = (torch.randn(R, C, generator=g) * torch.exp(torch.randn(R, 1, generator=g))).to(torch.bfloat16)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(torch.bfloat16)
+    eps = 1e-5
+    y_ref, rstd_ref = O.rmsnorm_f32(bf16_bits(x), bf16_bits(gamma), eps)
+    rstd = ops.rmsnorm_stats(x.to(dev), eps)
+    np.testing.assert_allclose(rstd.cpu().numpy(), rstd_ref, rtol=2e-6)
+    scale = np.float32(32.0)
+    amax = torch.zeros(1, dtype=torch.float32, device=dev)
+    y8, y8t = ops.norm_cast(x.to(dev), rstd, gamma.to(dev), _f32(scale, dev), amax, O.E4M3)
+    want = O.fp8_encode_sat((y_ref * scale).astype(np.float32), O.E4M3)
+    _ulp_close_fp8(u8(y8), want, O.E4M3)
+    np.testing.assert_array_equal(u8(y8t), u8(y8).T)
+    np.testing.assert_allclose(amax.item(), np.abs(y_ref).max(), rtol=1e-5)
+    dy = (torch.randn(R, C, generator=g) / 8).to(torch.bfloat16)
+    dx, dgam = ops.rmsnorm_bwd(dy.to(dev), x.to(dev), rstd, gamma.to(dev))
+    dx_ref, dg_ref = O.rmsnorm_bwd_f32(bf16_bits(dy), bf16_bits(x), bf16_bits(gamma), eps)
+    assert np.all(np.abs(dx.float().cpu().numpy() - dx_ref) <= 2.0 ** -7 * np.abs(dx_ref) + 1e-5 * np.abs(dx_ref).max())
+    np.testing.assert_allclose(dgam.cpu().numpy(), dg_ref, rtol=1e-4, atol=1e-4 * np.abs(dg_ref).max())
+    dx2, dgam2 = ops.rmsnorm_bwd(dy.to(dev), x.to(dev), rstd, gamma.to(dev))
+    assert torch.equal(dgam, dgam2) and torch.equal(dx, dx2)  # fixed-order partial sums: reproducible

@@ -342,3 +342,40 @@ def test_clipped_adamw_matches_torch_clip_plus_fused_adamw(dev):
             d = (x.float() - y.float()).abs()
             assert (d <= 2.0 ** -6 * y.float().abs() + 1e-3).all(), f"step {step}: max diff {d.max().item()}"  # <= 1-2 bf16 ulps
     assert (torch.cat([(x.float() - y.float()).abs().reshape(-1) for x, y in zip(pa, pb)]) == 0).float().mean() > 0.9
+
+
+def test_fused_rmsnorm_paths_match_unfused(te, dev):
+    """K9 (RMSNorm fused into the FP8 cast + HIP backward) vs torch rms_norm followed by the plain cast: the fused path
+    skips the bf16 rounding of the normalised activation, everything else is identical."""
+    DelayedScaling, Format, _ = _recipes()
+    recipe = DelayedScaling(fp8_format=Format.HYBRID, amax_history_len=4, amax_compute_algo="max")
+    h = 512
+    torch.manual_seed(21)
+    mods = []
+    for fused in (True, False):
+        lnl = te.LayerNormLinear(h, 768, eps=1e-5, bias=False, normalization="RMSNorm", parameters_split={"query_": 512, "key_": 128, "value_": 128},
+                                 params_dtype=torch.bfloat16, device=dev)
+        mlp = te.LayerNormMLP(h, 1024, normalization="RMSNorm", activation="swiglu", params_dtype=torch.bfloat16, device=dev)
+        lnl.fused_norm = mlp.fused_norm = fused
+        mods.append((lnl, mlp))
+    mods[1][0].load_state_dict(mods[0][0].state_dict()); mods[1][1].load_state_dict(mods[0][1].state_dict())
+    with torch.no_grad():
+        for lnl, mlp in mods:
+            lnl.layer_norm_weight.copy_(torch.linspace(0.5, 1.5, h)); mlp.layer_norm_weight.copy_(torch.linspace(1.5, 0.5, h))
+    x = torch.randn(2, 64, h, device=dev, dtype=torch.bfloat16)
+    for step in range(3):
+        outs = []
+        for lnl, mlp in mods:
+            xi = x.clone().requires_grad_(True)
+            with te.fp8_autocast(enabled=True, fp8_recipe=recipe):
+                y = lnl(xi)
+                z = mlp(xi)
+            (y.float().pow(2).mean() + z.float().pow(2).mean()).backward()
+            outs.append((y, z, xi.grad, lnl.layer_norm_weight.grad.clone(), mlp.layer_norm_weight.grad.clone(), lnl.key_weight.grad.clone()))
+            for p in list(lnl.parameters()) + list(mlp.parameters()):
+                p.grad = None
+        for a, b, name in zip(outs[0], outs[1], ("y", "z", "dx", "dgamma_qkv", "dgamma_mlp", "dw_k")):
+            rel = (a.float() - b.float()).norm() / b.float().norm()
+            if step > 0:  # step 0 quantises with scale 1 (tiny gradients land in the FP8 subnormals): not comparable
+                assert rel < 0.05, f"step {step} {name}: rel {rel:.4f}"  # FP8 re-quantisation noise of one bf16-ulp input change
+    assert torch.equal(mods[0][0]._meta_fwd.state()["scale"][1:2], mods[1][0]._meta_fwd.state()["scale"][1:2])
