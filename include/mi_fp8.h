@@ -156,6 +156,18 @@ int mi_rmsnorm_bwd(const void* dy_bf16, const void* x_bf16, const float* rstd, c
                    int64_t cols, void* stream);
 
 /*
+ * Token cross-entropy on the bf16 logits of the FP8 lm_head (the loss of the reference loop, HF ForCausalLMLoss:
+ * mean over tokens whose label != -100; train_fp8.py:278-279 `outputs.loss`), without an fp32 copy of the logits.
+ *   mi_ce_forward : lse[r] = log sum_c exp(x[r,c]); loss_rows[r] = lse[r] - x[r, labels[r]] (0 where the label is ignored)
+ *   mi_ce_backward: dlogits[r,c] = (exp(x[r,c] - lse[r]) - [c == labels[r]]) * *gscale (0 on ignored rows);
+ *                   *gscale = upstream gradient / number of valid tokens (device scalar).  cols % 8 == 0.
+ */
+int mi_ce_forward(const void* logits_bf16, const int64_t* labels, float* lse, float* loss_rows, int64_t rows,
+                  int64_t cols, void* stream);
+int mi_ce_backward(const void* logits_bf16, const int64_t* labels, const float* lse, const float* gscale,
+                   void* dlogits_bf16, int64_t rows, int64_t cols, void* stream);
+
+/*
  * Optimiser step of the reference loop (train_fp8.py:288-291: clip_grad_norm_(model.parameters(), 1.0) then
  * AdamW(fused=True).step()), used by llm_fp8_amd.train on the single-GPU path.
  *   mi_sumsq_bf16: partial[b] = sum of g^2 over block b's grid-stride share, b < n_partials (fixed order: reproducible).

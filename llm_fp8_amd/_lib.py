@@ -32,6 +32,8 @@ SIGNATURES = {
     "mi_rmsnorm_stats": [_p, _p, _c_i64, _c_i64, ctypes.c_float, _p],
     "mi_norm_cast": [_p, _p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],
     "mi_rmsnorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _c_int, _c_i64, _c_i64, _p],
+    "mi_ce_forward": [_p, _p, _p, _p, _c_i64, _c_i64, _p],
+    "mi_ce_backward": [_p, _p, _p, _p, _p, _c_i64, _c_i64, _p],
     "mi_sumsq_bf16": [_p, _c_i64, _p, _c_int, _p],
     "mi_adamw_bf16": [_p, _p, _p, _p, _c_i64, _p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                       ctypes.c_float, _c_i64, _p],

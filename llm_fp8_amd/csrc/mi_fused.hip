@@ -375,6 +375,84 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const uint16_t* __rest
     dgp[(int64_t)blockIdx.x * cols + c] = (s_dg[c] + s_dg[cols + c]) + (s_dg[2 * cols + c] + s_dg[3 * cols + c]);
 }
 
+// ------------------------------------------------------------------------------------------------ cross-entropy
+// The loss the reference trains with (HF ForCausalLMLoss: mean token cross-entropy, ignore_index = -100) on the bf16
+// logits of the FP8 lm_head, without the fp32 copy of the [tokens, vocab] logits: one workgroup per row.
+//   forward : lse[r] = log sum_c exp(x[r,c]) (online max/sum, fp32), loss[r] = lse[r] - x[r,label] (0 if ignored)
+//   backward: dx[r,c] = (exp(x[r,c] - lse[r]) - [c == label]) * *gscale   (0 for ignored rows)
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const uint16_t* __restrict__ x, const int64_t* __restrict__ labels,
+                                                     float* __restrict__ lse, float* __restrict__ loss, int cols) {
+  __shared__ float s_m[4], s_s[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const uint16_t* xr = x + (int64_t)row * cols;
+  float m = -INFINITY, ssum = 0.0f;
+  for (int c = tid * 8; c < cols; c += 2048) {
+    const v4i v = *reinterpret_cast<const v4i*>(xr + c);
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f[2 * j] = __uint_as_float((u32)v[j] << 16);
+      f[2 * j + 1] = __uint_as_float((u32)v[j] & 0xFFFF0000u);
+    }
+    float vm = f[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) vm = fmaxf(vm, f[j]);
+    const float nm = fmaxf(m, vm);
+    float add = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) add += __expf(f[j] - nm);
+    ssum = ssum * __expf(m - nm) + add;
+    m = nm;
+  }
+  // combine (m, ssum) across the wave, then across the 4 waves
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const float om = __shfl_xor(m, o), os = __shfl_xor(ssum, o);
+    const float nm = fmaxf(m, om);
+    ssum = (nm == -INFINITY) ? 0.0f : ssum * __expf(m - nm) + os * __expf(om - nm);
+    m = nm;
+  }
+  if ((tid & 63) == 0) { s_m[tid >> 6] = m; s_s[tid >> 6] = ssum; }
+  __syncthreads();
+  if (tid == 0) {
+    float M = s_m[0], S = s_s[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float nm = fmaxf(M, s_m[w]);
+      S = S * __expf(M - nm) + s_s[w] * __expf(s_m[w] - nm);
+      M = nm;
+    }
+    const float l = M + __logf(S);
+    lse[row] = l;
+    const int64_t lab = labels[row];
+    loss[row] = (lab >= 0 && lab < cols) ? l - bf16_bits_to_float(xr[lab]) : 0.0f;
+  }
+}
+
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const uint16_t* __restrict__ x, const int64_t* __restrict__ labels,
+                                                     const float* __restrict__ lse, const float* __restrict__ gscale,
+                                                     uint16_t* __restrict__ dx, int cols) {
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const int64_t lab = labels[row];
+  const bool valid = lab >= 0 && lab < cols;
+  const float gs = valid ? *gscale : 0.0f;
+  const float l = lse[row];
+  const uint16_t* xr = x + (int64_t)row * cols;
+  uint16_t* dr = dx + (int64_t)row * cols;
+  for (int c = tid * 8; c < cols; c += 2048) {
+    const v4i v = *reinterpret_cast<const v4i*>(xr + c);
+    v4i o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float p0 = __expf(__uint_as_float((u32)v[j] << 16) - l), p1 = __expf(__uint_as_float((u32)v[j] & 0xFFFF0000u) - l);
+      if (c + 2 * j == lab) p0 -= 1.0f;
+      if (c + 2 * j + 1 == lab) p1 -= 1.0f;
+      o[j] = (int)pack_bf16x2(p0 * gs, p1 * gs);
+    }
+    *reinterpret_cast<v4i*>(dr + c) = o;
+  }
+}
+
 }  // namespace mi
 
 extern "C" int mi_rope_qkv(void* fused_bf16, void* q_bf16, void* k_bf16, void* v_bf16, const float* cos_tab,
@@ -500,5 +578,29 @@ extern "C" int mi_rmsnorm_bwd(const void* dy_bf16, const void* x_bf16, const flo
   }
 #undef MI_RB
   MI_CHECK_LAUNCH("mi_rmsnorm_bwd launch");
+  return MI_OK;
+}
+
+extern "C" int mi_ce_forward(const void* logits_bf16, const int64_t* labels, float* lse, float* loss_rows, int64_t rows,
+                             int64_t cols, void* stream) {
+  MI_CHECK_ARG(logits_bf16 && labels && lse && loss_rows, "mi_ce_forward: null pointer");
+  MI_CHECK_ARG(rows >= 0 && cols > 0 && cols % 8 == 0 && rows < (1LL << 31) && cols < (1LL << 31), "mi_ce_forward: bad shape (cols % 8)");
+  MI_CHECK_ARG(((uintptr_t)logits_bf16 % 16) == 0, "mi_ce_forward: logits must be 16-byte aligned");
+  if (rows == 0) return MI_OK;
+  hipLaunchKernelGGL(mi::ce_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)logits_bf16, labels,
+                     lse, loss_rows, (int)cols);
+  MI_CHECK_LAUNCH("mi_ce_forward launch");
+  return MI_OK;
+}
+
+extern "C" int mi_ce_backward(const void* logits_bf16, const int64_t* labels, const float* lse, const float* gscale,
+                              void* dlogits_bf16, int64_t rows, int64_t cols, void* stream) {
+  MI_CHECK_ARG(logits_bf16 && labels && lse && gscale && dlogits_bf16, "mi_ce_backward: null pointer");
+  MI_CHECK_ARG(rows >= 0 && cols > 0 && cols % 8 == 0 && rows < (1LL << 31) && cols < (1LL << 31), "mi_ce_backward: bad shape (cols % 8)");
+  MI_CHECK_ARG(((uintptr_t)logits_bf16 % 16) == 0 && ((uintptr_t)dlogits_bf16 % 16) == 0, "mi_ce_backward: misaligned pointer");
+  if (rows == 0) return MI_OK;
+  hipLaunchKernelGGL(mi::ce_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)logits_bf16, labels,
+                     lse, gscale, (uint16_t*)dlogits_bf16, (int)cols);
+  MI_CHECK_LAUNCH("mi_ce_backward launch");
   return MI_OK;
 }

@@ -74,6 +74,12 @@ def prepare_model(model: torch.nn.Module, cfg: TrainingConfig) -> torch.nn.Modul
         llama.convert_model(model)  # lm_head with --use_te; every q/k/v/o/gate/up/down/lm_head without it
         recipe = llama.outer_recipe_for_scenario(cfg.fp8_scenario) if cfg.use_te else None
         llama.apply_fp8_autowrap(model, recipe)
+    if torch.cuda.is_available() and os.environ.get("LLM_FP8_AMD_HF_LOSS") != "1":
+        from .loss import causal_lm_loss
+        try:
+            model.loss_function = causal_lm_loss  # HF resolves `self.loss_function(logits=..., labels=..., vocab_size=...)`
+        except Exception:
+            model._loss_function = causal_lm_loss
     inner = model.forward
 
     def forward(*args, **kwargs):

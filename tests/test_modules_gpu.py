@@ -379,3 +379,23 @@ def test_fused_rmsnorm_paths_match_unfused(te, dev):
             if step > 0:  # step 0 quantises with scale 1 (tiny gradients land in the FP8 subnormals): not comparable
                 assert rel < 0.05, f"step {step} {name}: rel {rel:.4f}"  # FP8 re-quantisation noise of one bf16-ulp input change
     assert torch.equal(mods[0][0]._meta_fwd.state()["scale"][1:2], mods[1][0]._meta_fwd.state()["scale"][1:2])
+
+
+def test_fused_causal_lm_loss_matches_hf(dev):
+    from transformers.loss.loss_utils import ForCausalLMLoss
+    from llm_fp8_amd.loss import causal_lm_loss
+    torch.manual_seed(0)
+    B, S, V = 3, 40, 4096
+    logits = (torch.randn(B, S, V, device=dev) * 3).to(torch.bfloat16)
+    labels = torch.randint(0, V, (B, S), device=dev)
+    labels[0, 5:9] = -100
+    la = logits.clone().requires_grad_(True)
+    lb = logits.clone().requires_grad_(True)
+    a = causal_lm_loss(la, labels, V)
+    b = ForCausalLMLoss(lb, labels, V)
+    assert abs(a.item() - b.item()) <= 2e-4 * abs(b.item())
+    (a * 2.0).backward()
+    (b * 2.0).backward()
+    d = (la.grad.float() - lb.grad.float()).abs()
+    assert (d <= 2.0 ** -7 * lb.grad.float().abs() + 1e-7).all()
+    assert la.grad[0, 4:8].abs().sum().item() == 0  # rows whose shifted label is ignored get no gradient
