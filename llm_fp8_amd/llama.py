@@ -199,6 +199,46 @@ def replace_params(hf_state_dict, te_state_dict, config):
     return prefixes
 
 
+def to_hf_state_dict(te_state_dict, config, keep_extra: bool = False):
+    """Inverse of `replace_params`: TE-named decoder parameters -> HF Llama names, so a model
+    trained here saves a checkpoint vanilla `LlamaForCausalLM` can load (the reference's `save_pretrained` writes the
+    TE names, train_fp8.py:657-681, which HF cannot read back).  The zero-initialised TE-only MLP biases are dropped if
+    they are still all-zero and refused otherwise (HF Llama has `mlp_bias=False`); FP8 `_extra_state` blobs are
+    dropped unless `keep_extra`."""
+    out = {}
+    f = config.intermediate_size
+    simple = {
+        "self_attention.layernorm_qkv.layer_norm_weight": "input_layernorm.weight",
+        "self_attention.layernorm_qkv.query_weight": "self_attn.q_proj.weight",
+        "self_attention.layernorm_qkv.key_weight": "self_attn.k_proj.weight",
+        "self_attention.layernorm_qkv.value_weight": "self_attn.v_proj.weight",
+        "self_attention.proj.weight": "self_attn.o_proj.weight",
+        "layernorm_mlp.layer_norm_weight": "post_attention_layernorm.weight",
+        "layernorm_mlp.fc2_weight": "mlp.down_proj.weight",
+    }
+    for k, v in te_state_dict.items():
+        m = re.match(r"(model\.layers\.\d+\.)(.*)", k)
+        if k.endswith("_extra_state"):
+            if keep_extra:
+                out[k] = v
+            continue
+        if m is None:
+            out[k] = v
+            continue
+        prefix, name = m.group(1), m.group(2)
+        if name in simple:
+            out[prefix + simple[name]] = v
+        elif name == "layernorm_mlp.fc1_weight":
+            out[prefix + "mlp.gate_proj.weight"] = v[:f]
+            out[prefix + "mlp.up_proj.weight"] = v[f:]
+        elif name in ("layernorm_mlp.fc1_bias", "layernorm_mlp.fc2_bias"):
+            if bool(torch.count_nonzero(v)):
+                raise ValueError(f"{k} is non-zero: HF Llama has no MLP bias to hold it")
+        else:
+            out[k] = v
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------------
 # The two accelerate steps of Accelerator.prepare the reference depends on (accelerator.py:2098-2131,1818-1833).
 # accelerate's own FP8 path needs an installed `transformer_engine` distribution, so the harness does them itself.

@@ -36,14 +36,44 @@ def _as_bf16_2d(t: torch.Tensor) -> torch.Tensor:
 
 class _GemmSpec:
     """Everything non-tensor a GEMM site needs: recipe, meta windows, slot base, update trigger."""
-    __slots__ = ("recipe", "meta_fwd", "meta_bwd", "g", "fmt_fwd", "fmt_bwd", "trigger_bwd_update", "training", "eps")
+    __slots__ = ("recipe", "meta_fwd", "meta_bwd", "g", "fmt_fwd", "fmt_bwd", "trigger_bwd_update", "training", "eps",
+                 "wcache", "first_mb")
 
-    def __init__(self, recipe, meta_fwd, meta_bwd, g, trigger_bwd_update, training, eps=1e-5):
+    def __init__(self, recipe, meta_fwd, meta_bwd, g, trigger_bwd_update, training, eps=1e-5, wcache=None, first_mb=None):
         self.eps = eps
+        # FP8 weight caching across micro-batches (TE `is_first_microbatch`, SURVEY.md 8f rank 3): None = cast every
+        # forward (what the reference does), True = cast and keep, False = reuse the kept FP8 weights and their scale_inv
+        self.wcache, self.first_mb = wcache, first_mb
         self.recipe, self.meta_fwd, self.meta_bwd, self.g = recipe, meta_fwd, meta_bwd, g
         self.fmt_fwd, self.fmt_bwd = fmt_codes(recipe.fp8_format)
         self.trigger_bwd_update = trigger_bwd_update
         self.training = training
+
+
+def _cast_weights(spec: _GemmSpec, g: int, weights, ns, N: int, K: int, dev, need_t: bool):
+    """FP8 copies (w8 [N,K], w8T [K,N]) of the concatenated weight parts of GEMM `g` under delayed scaling, plus the
+    scale_inv they were quantised with.  Honours the micro-batch cache of the spec (see _GemmSpec)."""
+    mf = spec.meta_fwd
+    ck = ("ds", g)
+    if spec.first_mb is False and spec.wcache is not None:
+        hit = spec.wcache.get(ck)
+        if hit is not None and (hit[1] is not None or not need_t):
+            return hit
+    keep = spec.first_mb is True and spec.wcache is not None
+    want_t = need_t or keep
+    w8 = torch.empty((N, K), dtype=torch.uint8, device=dev)
+    w8t = torch.empty((K, N), dtype=torch.uint8, device=dev) if want_t else None
+    r = 0
+    for w, n in zip(weights, ns):
+        wb = w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)
+        ops.cast_amax(wb.contiguous(), mf.scale(3 * g + 1), mf.amax(3 * g + 1), spec.fmt_fwd,
+                      y=w8[r:r + n], yT=None if w8t is None else w8t[:, r:r + n], want_t=want_t)
+        r += n
+    siw = mf.scale_inv(3 * g + 1)
+    if keep:
+        siw = siw.clone()
+        spec.wcache[ck] = (w8, w8t, siw)
+    return w8, w8t, siw
 
 
 class _FP8LinearFn(torch.autograd.Function):
@@ -70,7 +100,15 @@ class _FP8LinearFn(torch.autograd.Function):
             wcat = weights[0] if len(weights) == 1 else torch.cat(list(weights), 0)
             wcat = wcat if wcat.dtype == torch.bfloat16 else wcat.to(torch.bfloat16)
             x8, xs, xt8, xts = ops.mxfp8_quantize(x2, spec.fmt_fwd, rowwise=True, colwise=need_wgrad)
-            w8, ws, wt8, wts = ops.mxfp8_quantize(wcat.contiguous(), spec.fmt_fwd, rowwise=True, colwise=need_dgrad)
+            ck = ("mx", spec.g)
+            hit = spec.wcache.get(ck) if (spec.first_mb is False and spec.wcache is not None) else None
+            if hit is not None and (hit[2] is not None or not need_dgrad):
+                w8, ws, wt8, wts = hit
+            else:
+                w8, ws, wt8, wts = ops.mxfp8_quantize(wcat.contiguous(), spec.fmt_fwd, rowwise=True,
+                                                      colwise=need_dgrad or spec.first_mb is True)
+                if spec.first_mb is True and spec.wcache is not None:
+                    spec.wcache[ck] = (w8, ws, wt8, wts)
             y = ops.gemm_mxfp8(x8, xs, w8, ws, spec.fmt_fwd, spec.fmt_fwd, bias=bias_bf16)
             ctx.saved_fp8 = (xt8, xts, wt8, wts, None)
         else:
@@ -83,18 +121,12 @@ class _FP8LinearFn(torch.autograd.Function):
                     ctx.norm = (x2, rstd, gam, ln_w.dtype)
             else:
                 x8, x8t = ops.cast_amax(x2, mf.scale(3 * g), mf.amax(3 * g), spec.fmt_fwd, want_t=need_wgrad)
-            w8 = torch.empty((N, K), dtype=torch.uint8, device=dev)
-            w8t = torch.empty((K, N), dtype=torch.uint8, device=dev) if need_dgrad else None
-            r = 0
-            for w, n in zip(weights, ns):
-                wb = w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)
-                ops.cast_amax(wb.contiguous(), mf.scale(3 * g + 1), mf.amax(3 * g + 1), spec.fmt_fwd,
-                              y=w8[r:r + n], yT=None if w8t is None else w8t[:, r:r + n], want_t=need_dgrad)
-                r += n
-            y = ops.gemm_fp8(x8, w8, mf.scale_inv(3 * g), mf.scale_inv(3 * g + 1), spec.fmt_fwd, spec.fmt_fwd,
-                             bias=bias_bf16)
+            w8, w8t, siw = _cast_weights(spec, g, weights, ns, N, K, dev, need_dgrad)
+            y = ops.gemm_fp8(x8, w8, mf.scale_inv(3 * g), siw, spec.fmt_fwd, spec.fmt_fwd, bias=bias_bf16)
             # scale_inv as of quantisation time: the arena is updated at autocast exit, before backward
             sinv = mf.scale_inv_snapshot() if (need_wgrad or need_dgrad) else None
+            if sinv is not None:
+                sinv[3 * g + 1:3 * g + 2].copy_(siw)
             ctx.saved_fp8 = (x8t, None, w8t, None, sinv)
         ctx.spec, ctx.ns, ctx.x_shape, ctx.x_dtype = spec, ns, x.shape, x.dtype
         ctx.w_dtypes = [w.dtype for w in weights]
@@ -170,16 +202,19 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
                 ctx.norm = (x2, rstd, gam, ln_w.dtype)
         else:
             x8, x8t = ops.cast_amax(x2, mf.scale(0), mf.amax(0), fmt, want_t=need_w)
-        w1b = (w1 if w1.dtype == torch.bfloat16 else w1.to(torch.bfloat16)).contiguous()
-        w1_8, w1_8t = ops.cast_amax(w1b, mf.scale(1), mf.amax(1), fmt, want_t=bwd)
-        h = ops.gemm_fp8(x8, w1_8, mf.scale_inv(0), mf.scale_inv(1), fmt, fmt,
+        dev = x2.device
+        w1_8, w1_8t, si1 = _cast_weights(spec, 0, (w1,), [w1.shape[0]], w1.shape[0], K, dev, bwd)
+        h = ops.gemm_fp8(x8, w1_8, mf.scale_inv(0), si1, fmt, fmt,
                          bias=None if b1 is None else b1.to(torch.bfloat16).contiguous())
         a8, a8t = ops.swiglu_cast(h, mf.scale(3), mf.amax(3), fmt, want_t=need_w)
-        w2b = (w2 if w2.dtype == torch.bfloat16 else w2.to(torch.bfloat16)).contiguous()
-        w2_8, w2_8t = ops.cast_amax(w2b, mf.scale(4), mf.amax(4), fmt, want_t=bwd)
-        y = ops.gemm_fp8(a8, w2_8, mf.scale_inv(3), mf.scale_inv(4), fmt, fmt,
+        w2_8, w2_8t, si2 = _cast_weights(spec, 1, (w2,), [w2.shape[0]], w2.shape[0], w2.shape[1], dev, bwd)
+        y = ops.gemm_fp8(a8, w2_8, mf.scale_inv(3), si2, fmt, fmt,
                          bias=None if b2 is None else b2.to(torch.bfloat16).contiguous())
-        ctx.saved_fp8 = (x8t, w1_8t, a8t, w2_8t, h if bwd else None, mf.scale_inv_snapshot() if bwd else None)
+        sinv = mf.scale_inv_snapshot() if bwd else None
+        if sinv is not None:
+            sinv[1:2].copy_(si1)
+            sinv[4:5].copy_(si2)
+        ctx.saved_fp8 = (x8t, w1_8t, a8t, w2_8t, h if bwd else None, sinv)
         ctx.spec, ctx.x_shape, ctx.x_dtype = spec, x.shape, x.dtype
         ctx.dtypes = (w1.dtype, None if b1 is None else b1.dtype, w2.dtype, None if b2 is None else b2.dtype)
         ctx.need_dgrad, ctx.need_w = need_dgrad, need_w
@@ -233,6 +268,7 @@ class _FP8Module(torch.nn.Module):
         self._meta_bwd: Optional[ModuleMeta] = None
         self._meta_key = None
         self._pending_state = None
+        self._wcache = {}  # FP8 weights kept across micro-batches (is_first_microbatch protocol)
 
     def _prepare(self, device) -> Optional[Tuple[Recipe, Optional[ModuleMeta], Optional[ModuleMeta], bool]]:
         """Called at the top of forward.  None -> run the plain bf16 path."""
@@ -337,7 +373,7 @@ class Linear(_FP8Module):
         if st is None:
             return F.linear(inp, self.weight.to(inp.dtype), None if self.bias is None else self.bias.to(inp.dtype))
         recipe, mf, mb, first = st
-        spec = _GemmSpec(recipe, mf, mb, 0, first, self.training)
+        spec = _GemmSpec(recipe, mf, mb, 0, first, self.training, wcache=self._wcache, first_mb=is_first_microbatch)
         return _FP8LinearFn.apply(inp, self.bias, spec, None, self.weight)
 
     def extra_repr(self):
@@ -404,15 +440,16 @@ class LayerNormLinear(_FP8Module):
         ws, b = self._weights(), self._bias()
         if st is not None and _can_fuse_norm(self, st[0], inp) and not self.return_layernorm_output:
             recipe, mf, mb, first = st
-            return _FP8LinearFn.apply(inp, b, _GemmSpec(recipe, mf, mb, 0, first, self.training, self.eps),
-                                      self.layer_norm_weight, *ws)
+            return _FP8LinearFn.apply(inp, b, _GemmSpec(recipe, mf, mb, 0, first, self.training, self.eps, self._wcache,
+                                                        is_first_microbatch), self.layer_norm_weight, *ws)
         ln = self._norm(inp)
         if st is None:
             w = ws[0] if len(ws) == 1 else torch.cat(ws, 0)
             out = F.linear(ln, w.to(ln.dtype), None if b is None else b.to(ln.dtype))
         else:
             recipe, mf, mb, first = st
-            out = _FP8LinearFn.apply(ln, b, _GemmSpec(recipe, mf, mb, 0, first, self.training), None, *ws)
+            out = _FP8LinearFn.apply(ln, b, _GemmSpec(recipe, mf, mb, 0, first, self.training, wcache=self._wcache,
+                                                      first_mb=is_first_microbatch), None, *ws)
         return (out, ln) if self.return_layernorm_output else out
 
 
@@ -472,7 +509,8 @@ class LayerNormMLP(_FP8Module):
         if (st is not None and self.activation == "swiglu" and self.fused_swiglu and _can_fuse_norm(self, st[0], inp)):
             recipe, mf, mb, first = st  # K9 + K10: norm -> cast, fc1, SwiGLU -> cast, fc2 in one autograd node
             return _FP8SwiGLUMLPFn.apply(inp, self.fc1_weight, self.fc1_bias, self.fc2_weight, self.fc2_bias,
-                                         _GemmSpec(recipe, mf, mb, 0, first, self.training, self.eps), self.layer_norm_weight)
+                                         _GemmSpec(recipe, mf, mb, 0, first, self.training, self.eps, self._wcache,
+                                                   is_first_microbatch), self.layer_norm_weight)
         ln = self._norm(inp)
         if st is None:
             h = F.linear(ln, self.fc1_weight.to(ln.dtype), None if self.fc1_bias is None else self.fc1_bias.to(ln.dtype))
@@ -481,8 +519,11 @@ class LayerNormMLP(_FP8Module):
         recipe, mf, mb, first = st
         if self.activation == "swiglu" and recipe.delayed() and self.fused_swiglu:
             return _FP8SwiGLUMLPFn.apply(ln, self.fc1_weight, self.fc1_bias, self.fc2_weight, self.fc2_bias,
-                                         _GemmSpec(recipe, mf, mb, 0, first, self.training))
+                                         _GemmSpec(recipe, mf, mb, 0, first, self.training, wcache=self._wcache,
+                                                   first_mb=is_first_microbatch))
         # fc1's backward is the last FP8 op of this module's backward -> it carries the update trigger
-        h = _FP8LinearFn.apply(ln, self.fc1_bias, _GemmSpec(recipe, mf, mb, 0, first, self.training), None, self.fc1_weight)
+        h = _FP8LinearFn.apply(ln, self.fc1_bias, _GemmSpec(recipe, mf, mb, 0, first, self.training, wcache=self._wcache,
+                                                            first_mb=is_first_microbatch), None, self.fc1_weight)
         a = self.act_fn(h)
-        return _FP8LinearFn.apply(a, self.fc2_bias, _GemmSpec(recipe, mf, mb, 1, False, self.training), None, self.fc2_weight)
+        return _FP8LinearFn.apply(a, self.fc2_bias, _GemmSpec(recipe, mf, mb, 1, False, self.training, wcache=self._wcache,
+                                                              first_mb=is_first_microbatch), None, self.fc2_weight)

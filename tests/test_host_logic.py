@@ -1,0 +1,66 @@
+"""CPU: host-side logic that needs no GPU -- recipes, state-dict mapping both ways, tile picking rules mirrored in Python."""
+import pytest
+import torch
+
+
+def test_recipe_surface_matches_te_defaults():
+    from llm_fp8_amd.common.recipe import DelayedScaling, Format, MXFP8BlockScaling, fmt_codes
+    r = DelayedScaling()
+    assert r.fp8_format is Format.HYBRID and r.amax_history_len == 1024 and r.amax_compute_algo == "max" and r.margin == 0
+    assert Format.HYBRID.value.max_fwd == 448.0 and Format.HYBRID.value.max_bwd == 57344.0 and Format.E4M3.value.max_bwd == 448.0
+    assert fmt_codes(Format.HYBRID) == (0, 1) and fmt_codes(Format.E4M3) == (0, 0) and fmt_codes(Format.E5M2) == (1, 1)
+    assert MXFP8BlockScaling().mxfp8() and not r.mxfp8() and r.delayed()
+    with pytest.raises(ValueError):
+        DelayedScaling(amax_compute_algo="median")
+    # accelerate's TERecipeKwargs call shape (utils/transformer_engine.py:156-177)
+    DelayedScaling(margin=0, interval=1, fp8_format=Format.E4M3, amax_history_len=16, amax_compute_algo="max",
+                   override_linear_precision=(False, False, False))
+
+
+def test_scenario_recipes_follow_the_three_reference_files():
+    from llm_fp8_amd import llama
+    from llm_fp8_amd.common.recipe import Format
+    a, m = llama.scenario_recipes("default")      # te_llama.py:39-40
+    assert a.fp8_format is Format.HYBRID and m.fp8_format is Format.E4M3 and a.amax_history_len == m.amax_history_len == 16
+    a, m = llama.scenario_recipes("hybrid")       # te_llama_hybrid.py:39
+    assert a is m and a.fp8_format is Format.HYBRID
+    a, m = llama.scenario_recipes("mxfp8")        # te_llama_mxfp8.py:28-29
+    assert a is m and a.mxfp8() and a.fp8_format is Format.E4M3
+    o = llama.outer_recipe_for_scenario("default")  # train_fp8.py:144-146 -> TERecipeKwargs() defaults
+    assert o.fp8_format is Format.HYBRID and o.amax_history_len == 1024 and o.amax_compute_algo == "most_recent"
+    o = llama.outer_recipe_for_scenario("mxfp8")    # train_fp8.py:158-165
+    assert o.fp8_format is Format.E4M3 and o.amax_history_len == 16 and o.delayed()
+
+
+def test_replace_params_and_its_inverse_roundtrip():
+    from transformers.models.llama.modeling_llama import LlamaForCausalLM
+    from llm_fp8_amd import llama
+    cfg = llama.llama_config("llama-3.2-1b", num_hidden_layers=2, hidden_size=64, intermediate_size=128, num_attention_heads=4,
+                             num_key_value_heads=2, head_dim=16, vocab_size=128, max_position_embeddings=64)
+    torch.manual_seed(0)
+    hf = LlamaForCausalLM(cfg)
+    te_model = llama.TELlamaForCausalLM.from_hf_state_dict(hf.state_dict(), cfg, "default", torch_dtype=torch.float32)
+    sd = te_model.state_dict()
+    assert "model.layers.1.layernorm_mlp.fc1_weight" in sd and "model.layers.0.self_attention.layernorm_qkv.key_weight" in sd
+    assert "model.layers.0.layernorm_mlp.fc1_bias" in sd  # TE-only parameters
+    back = llama.to_hf_state_dict(sd, cfg)
+    ref = hf.state_dict()
+    assert set(back.keys()) == set(ref.keys())
+    for k in ref:
+        assert torch.equal(back[k].float(), ref[k].float()), k
+    hf2 = LlamaForCausalLM(cfg)
+    hf2.load_state_dict(back)  # vanilla HF can load what we save
+    sd["model.layers.0.layernorm_mlp.fc2_bias"] = torch.ones_like(sd["model.layers.0.layernorm_mlp.fc2_bias"])
+    with pytest.raises(ValueError, match="no MLP bias"):
+        llama.to_hf_state_dict(sd, cfg)
+
+
+def test_llama_config_table():
+    from llm_fp8_amd import llama
+    c = llama.llama_config("meta-llama/Llama-3.2-3B")
+    assert (c.hidden_size, c.intermediate_size, c.num_hidden_layers, c.num_attention_heads, c.num_key_value_heads, c.head_dim) == (3072, 8192, 28, 24, 8, 128)
+    assert c.vocab_size == 128256 and c.tie_word_embeddings
+    c = llama.llama_config("llama-3.1-8b")
+    assert (c.hidden_size, c.intermediate_size, c.num_hidden_layers) == (4096, 14336, 32) and not c.tie_word_embeddings
+    with pytest.raises(KeyError):
+        llama.llama_config("gpt-2")

@@ -399,3 +399,39 @@ def test_fused_causal_lm_loss_matches_hf(dev):
     d = (la.grad.float() - lb.grad.float()).abs()
     assert (d <= 2.0 ** -7 * lb.grad.float().abs() + 1e-7).all()
     assert la.grad[0, 4:8].abs().sum().item() == 0  # rows whose shifted label is ignored get no gradient
+
+
+@pytest.mark.parametrize("kind", ["linear", "mlp", "mx"])
+def test_is_first_microbatch_reuses_fp8_weights(te, dev, kind):
+    """TE's micro-batch protocol: is_first_microbatch=True casts and keeps the FP8 weights,
+    False reuses them -- no weight-cast launches -- and gives the same result as re-casting unchanged weights."""
+    from llm_fp8_amd.pytorch.profiler import KernelTimer
+    DelayedScaling, Format, MXFP8BlockScaling = _recipes()
+    recipe = MXFP8BlockScaling() if kind == "mx" else DelayedScaling(fp8_format=Format.HYBRID, amax_history_len=4, amax_compute_algo="max")
+    torch.manual_seed(2)
+    if kind == "mlp":
+        mod = te.LayerNormMLP(256, 512, normalization="RMSNorm", activation="swiglu", params_dtype=torch.bfloat16, device=dev)
+    else:
+        mod = te.Linear(256, 512, params_dtype=torch.bfloat16, device=dev)
+    x = torch.randn(64, 256, device=dev, dtype=torch.bfloat16, requires_grad=True)
+
+    def run(flag):
+        t = KernelTimer()
+        with t.install():
+            with te.fp8_autocast(enabled=True, fp8_recipe=recipe):
+                y = mod(x, is_first_microbatch=flag)
+            y.float().pow(2).mean().backward()
+        torch.cuda.synchronize()
+        s = t.summarize()
+        casts = sum(v["launches"] for k, v in s.items() if k in ("cast_amax", "mxfp8_quantize", "norm_cast"))
+        return y.detach().clone(), casts
+
+    run(None)  # settle the delayed scales a little
+    y_first, c_first = run(True)
+    y_reuse, c_reuse = run(False)
+    y_recast, c_recast = run(None)
+    n_w = 2 if kind == "mlp" else 1
+    assert c_reuse == c_first - n_w and c_recast == c_first
+    rel = (y_reuse.float() - y_recast.float()).norm() / y_recast.float().norm()
+    assert rel < 0.02  # weights unchanged: only the (delayed) scale the weights were quantised with differs
+    assert torch.isfinite(mod.fc1_weight.grad if kind == "mlp" else mod.weight.grad).all()
