@@ -102,6 +102,20 @@ int mi_mxfp8_quantize(const void* x_bf16, void* y_row, void* s_row, void* y_colT
                       int64_t rows, int64_t cols, int fmt, void* stream);
 
 /*
+ * K7 fused with the GEMM neighbours (MXFP8 counterparts of K9 / K10; same output layout as mi_mxfp8_quantize):
+ *   mi_mxfp8_norm_quantize     quantises (x * rstd[r]) * gamma[c]                      (RMSNorm -> MXFP8)
+ *   mi_mxfp8_swiglu_quantize   quantises silu(h[:, :F]) * h[:, F:]                     (outputs have F columns)
+ *   mi_mxfp8_dswiglu_quantize  quantises [dact*dsilu(g)*u | dact*silu(g)] ([rows, 2F]) and writes the per-128-row
+ *                              column sums (fp32 [ceil(rows/128), 2F], nullable) for the fc1 bias gradient
+ */
+int mi_mxfp8_norm_quantize(const void* x_bf16, const float* rstd, const void* gamma_bf16, void* y_row, void* s_row,
+                           void* y_colT, void* s_colT, int64_t rows, int64_t cols, int fmt, void* stream);
+int mi_mxfp8_swiglu_quantize(const void* h_bf16, void* y_row, void* s_row, void* y_colT, void* s_colT, int64_t rows,
+                             int64_t F, int fmt, void* stream);
+int mi_mxfp8_dswiglu_quantize(const void* h_bf16, const void* dact_bf16, void* y_row, void* s_row, void* y_colT,
+                              void* s_colT, float* colsum, int64_t rows, int64_t F, int fmt, void* stream);
+
+/*
  * K8  block-scaled MXFP8 GEMM (v_mfma_scale_f32_16x16x128_f8f6f4 with per-32 E8M0 scales)
  *   D[m,n] = bf16( sum_blk 2^(sa[m,blk]+sb[n,blk]-254) * sum_{k in blk} A[m,k] B[n,k] + bias[n] )
  * A [M,K] fp8 + SA [K/32, M] u8; B [N,K] fp8 + SB [K/32, N] u8 (block-major, as mi_mxfp8_quantize emits); K multiple of 32.

@@ -30,11 +30,22 @@ __device__ __forceinline__ float e8m0_inv(u32 e) {
   return __uint_as_float((254u - e) << 23);
 }
 
-template <int FMT, bool ROWWISE, bool COLWISE>
-__global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ y_row,
+// PRE selects what is quantised (the value block f[8][8] of this lane), so the neighbours of the GEMMs fuse into
+// the quantiser exactly as they do on the delayed-scaling path (K9 / K10):
+//   0  x[r,c]                                               x: [rows, cols]
+//   1  (x[r,c] * rstd[r]) * gamma[c]          (RMSNorm)     x: [rows, cols], aux32 = rstd, aux16 = gamma
+//   2  silu(h[r,c]) * h[r,F+c]                (SwiGLU)      x = h: [rows, 2*cols]
+//   3  dSwiGLU: [d*dsilu(g)*u | d*silu(g)]                  x = h: [rows, cols] (cols = 2F), aux16 = d: [rows, F];
+//      colsum[tile_r, c] = per-128-row column sums (fc1 bias gradient, fixed order)
+__device__ __forceinline__ float mx_sigmoid(float g) { return 1.0f / (1.0f + __expf(-g)); }
+
+template <int FMT, bool ROWWISE, bool COLWISE, int PRE>
+__global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ aux16,
+                                                          const float* __restrict__ aux32, uint8_t* __restrict__ y_row,
                                                           uint8_t* __restrict__ s_row, uint8_t* __restrict__ y_colT,
-                                                          uint8_t* __restrict__ s_colT, int rows, int cols,
-                                                          int tiles_c) {
+                                                          uint8_t* __restrict__ s_colT, float* __restrict__ colsum, int rows,
+                                                          int cols, int tiles_c) {
+  __shared__ float s_col[2][128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile_r = blockIdx.x / tiles_c, tile_c = blockIdx.x % tiles_c;
   const int r0 = tile_r * 128 + (wave >> 1) * 64 + (lane >> 3) * 8;
@@ -43,20 +54,103 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
   const bool active = (r0 < rows) && (c0 < cols);
   float f[8][8];  // values as cast
   float g[8][8];  // |values| with NaN -> 0, for the block amax (fmaxf semantics)
-  u32 screen = 0;
+  bool any_nan = false;
+  if (PRE == 0) {
+    u32 screen = 0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    v4i raw = {0, 0, 0, 0};
-    if (active) raw = *reinterpret_cast<const v4i*>(x + (int64_t)(r0 + i) * cols + c0);
+    for (int i = 0; i < 8; ++i) {
+      v4i raw = {0, 0, 0, 0};
+      if (active) raw = *reinterpret_cast<const v4i*>(x + (int64_t)(r0 + i) * cols + c0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      u32 w = (u32)raw[j];
-      screen = nan_screen(screen, w);
-      f[i][2 * j] = __uint_as_float(w << 16);
-      f[i][2 * j + 1] = __uint_as_float(w & 0xFFFF0000u);
+      for (int j = 0; j < 4; ++j) {
+        u32 w = (u32)raw[j];
+        screen = nan_screen(screen, w);
+        f[i][2 * j] = __uint_as_float(w << 16);
+        f[i][2 * j + 1] = __uint_as_float(w & 0xFFFF0000u);
+      }
+    }
+    any_nan = nan_seen(screen);
+  } else if (PRE == 1) {
+    float gm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (active) {
+      const v4i gv = *reinterpret_cast<const v4i*>(aux16 + c0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        gm[2 * j] = __uint_as_float((u32)gv[j] << 16);
+        gm[2 * j + 1] = __uint_as_float((u32)gv[j] & 0xFFFF0000u);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v4i raw = {0, 0, 0, 0};
+      float rs = 0.0f;
+      if (active) {
+        raw = *reinterpret_cast<const v4i*>(x + (int64_t)(r0 + i) * cols + c0);
+        rs = aux32[r0 + i];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        u32 w = (u32)raw[j];
+        f[i][2 * j] = (__uint_as_float(w << 16) * rs) * gm[2 * j];
+        f[i][2 * j + 1] = (__uint_as_float(w & 0xFFFF0000u) * rs) * gm[2 * j + 1];
+      }
+    }
+    any_nan = true;  // computed values: take the explicit NaN test below
+  } else {
+    const int F = PRE == 2 ? cols : cols / 2;
+    const bool up_half = (PRE == 3) && (c0 >= F);
+    const int cg = up_half ? c0 - F : c0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      v4i gv = {0, 0, 0, 0}, uv = {0, 0, 0, 0}, dv = {0, 0, 0, 0};
+      if (active) {
+        const int64_t r = r0 + i;
+        gv = *reinterpret_cast<const v4i*>(x + r * 2 * F + cg);
+        uv = *reinterpret_cast<const v4i*>(x + r * 2 * F + F + cg);
+        if (PRE == 3) dv = *reinterpret_cast<const v4i*>(aux16 + r * F + cg);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32 wg = (u32)gv[j], wu = (u32)uv[j], wd = (u32)dv[j];
+        const float g2[2] = {__uint_as_float(wg << 16), __uint_as_float(wg & 0xFFFF0000u)};
+        const float u2[2] = {__uint_as_float(wu << 16), __uint_as_float(wu & 0xFFFF0000u)};
+        const float d2[2] = {__uint_as_float(wd << 16), __uint_as_float(wd & 0xFFFF0000u)};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float sg = mx_sigmoid(g2[e]);
+          float v;
+          if (PRE == 2) v = g2[e] * sg * u2[e];
+          else if (!up_half) v = d2[e] * u2[e] * (sg * (1.0f + g2[e] * (1.0f - sg)));
+          else v = d2[e] * (g2[e] * sg);
+          f[i][2 * j + e] = v;
+        }
+      }
+    }
+    any_nan = true;
+    if (PRE == 3 && colsum != nullptr) {
+      float csum[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v += f[i][j];
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        csum[j] = v;
+      }
+      if ((lane >> 3) == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s_col[wave >> 1][(wave & 1) * 64 + (lane & 7) * 8 + j] = csum[j];
+      }
+      __syncthreads();
+      if (tid < 128) {
+        const int c = tile_c * 128 + tid;
+        if (c < cols) colsum[(int64_t)tile_r * cols + c] = s_col[0][tid] + s_col[1][tid];
+      }
     }
   }
-  if (__builtin_expect(nan_seen(screen), 0)) {
+  if (__builtin_expect(any_nan, PRE != 0)) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -137,38 +231,73 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
   }
 }
 
-template <int FMT>
-static int launch_mx(const void* x, void* y_row, void* s_row, void* y_colT, void* s_colT, int64_t rows, int64_t cols,
-                     hipStream_t st) {
+template <int FMT, int PRE>
+static int launch_mx(const void* x, const void* aux16, const float* aux32, void* y_row, void* s_row, void* y_colT, void* s_colT,
+                     float* colsum, int64_t rows, int64_t cols, hipStream_t st) {
   const int tiles_r = (int)((rows + 127) / 128), tiles_c = (int)((cols + 127) / 128);
   dim3 grid((unsigned)(tiles_r * tiles_c)), block(256);
-  const uint16_t* xp = (const uint16_t*)x;
+  const uint16_t *xp = (const uint16_t*)x, *ap = (const uint16_t*)aux16;
   uint8_t *yr = (uint8_t*)y_row, *sr = (uint8_t*)s_row, *yc = (uint8_t*)y_colT, *sc = (uint8_t*)s_colT;
   if (y_row && y_colT)
-    hipLaunchKernelGGL((mxfp8_quant_kernel<FMT, true, true>), grid, block, 0, st, xp, yr, sr, yc, sc, (int)rows, (int)cols, tiles_c);
+    hipLaunchKernelGGL((mxfp8_quant_kernel<FMT, true, true, PRE>), grid, block, 0, st, xp, ap, aux32, yr, sr, yc, sc, colsum, (int)rows, (int)cols, tiles_c);
   else if (y_row)
-    hipLaunchKernelGGL((mxfp8_quant_kernel<FMT, true, false>), grid, block, 0, st, xp, yr, sr, yc, sc, (int)rows, (int)cols, tiles_c);
+    hipLaunchKernelGGL((mxfp8_quant_kernel<FMT, true, false, PRE>), grid, block, 0, st, xp, ap, aux32, yr, sr, yc, sc, colsum, (int)rows, (int)cols, tiles_c);
   else
-    hipLaunchKernelGGL((mxfp8_quant_kernel<FMT, false, true>), grid, block, 0, st, xp, yr, sr, yc, sc, (int)rows, (int)cols, tiles_c);
+    hipLaunchKernelGGL((mxfp8_quant_kernel<FMT, false, true, PRE>), grid, block, 0, st, xp, ap, aux32, yr, sr, yc, sc, colsum, (int)rows, (int)cols, tiles_c);
   MI_CHECK_LAUNCH("mi_mxfp8_quantize launch");
   return MI_OK;
 }
 
 }  // namespace mi
 
+static int mx_common_check(const char* who, const void* x, const void* y_row, const void* s_row, const void* y_colT,
+                           const void* s_colT, int64_t rows, int64_t cols, int fmt) {
+  MI_CHECK_ARG(x, "%s: null input", who);
+  MI_CHECK_ARG((y_row && s_row) || (y_colT && s_colT), "%s: need (y_row,s_row) and/or (y_colT,s_colT)", who);
+  MI_CHECK_ARG((!y_row) == (!s_row) && (!y_colT) == (!s_colT), "%s: data and scale pointers must pair up", who);
+  MI_CHECK_ARG(rows >= 0 && cols >= 0 && rows % 32 == 0 && cols % 32 == 0,
+               "%s: rows (%lld) and cols (%lld) must be multiples of 32", who, (long long)rows, (long long)cols);
+  MI_CHECK_ARG(rows < (1LL << 31) && cols < (1LL << 31), "%s: shape too large", who);
+  MI_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y_row % 8) == 0 && ((uintptr_t)y_colT % 8) == 0 &&
+                   ((uintptr_t)s_row % 8) == 0 && ((uintptr_t)s_colT % 8) == 0, "%s: misaligned pointer", who);
+  MI_CHECK_ARG(fmt == MI_FMT_E4M3 || fmt == MI_FMT_E5M2, "%s: bad fmt %d", who, fmt);
+  return MI_OK;
+}
+
+#define MI_MX_DISPATCH(PRE, x, a16, a32, cs, rows, cols)                                                                       \
+  (fmt == MI_FMT_E4M3 ? mi::launch_mx<MI_FMT_E4M3, PRE>(x, a16, a32, y_row, s_row, y_colT, s_colT, cs, rows, cols, (hipStream_t)stream) \
+                      : mi::launch_mx<MI_FMT_E5M2, PRE>(x, a16, a32, y_row, s_row, y_colT, s_colT, cs, rows, cols, (hipStream_t)stream))
+
 extern "C" int mi_mxfp8_quantize(const void* x_bf16, void* y_row, void* s_row, void* y_colT, void* s_colT,
                                  int64_t rows, int64_t cols, int fmt, void* stream) {
-  MI_CHECK_ARG(x_bf16, "mi_mxfp8_quantize: null input");
-  MI_CHECK_ARG((y_row && s_row) || (y_colT && s_colT), "mi_mxfp8_quantize: need (y_row,s_row) and/or (y_colT,s_colT)");
-  MI_CHECK_ARG((!y_row) == (!s_row) && (!y_colT) == (!s_colT), "mi_mxfp8_quantize: data and scale pointers must pair up");
-  MI_CHECK_ARG(rows >= 0 && cols >= 0 && rows % 32 == 0 && cols % 32 == 0,
-               "mi_mxfp8_quantize: rows (%lld) and cols (%lld) must be multiples of 32", (long long)rows, (long long)cols);
-  MI_CHECK_ARG(rows < (1LL << 31) && cols < (1LL << 31), "mi_mxfp8_quantize: shape too large");
-  MI_CHECK_ARG(((uintptr_t)x_bf16 % 16) == 0 && ((uintptr_t)y_row % 8) == 0 && ((uintptr_t)y_colT % 8) == 0,
-               "mi_mxfp8_quantize: misaligned pointer");
-  MI_CHECK_ARG(fmt == MI_FMT_E4M3 || fmt == MI_FMT_E5M2, "mi_mxfp8_quantize: bad fmt %d", fmt);
+  int rc = mx_common_check("mi_mxfp8_quantize", x_bf16, y_row, s_row, y_colT, s_colT, rows, cols, fmt);
+  if (rc != MI_OK) return rc;
   if (rows == 0 || cols == 0) return MI_OK;
-  hipStream_t st = (hipStream_t)stream;
-  if (fmt == MI_FMT_E4M3) return mi::launch_mx<MI_FMT_E4M3>(x_bf16, y_row, s_row, y_colT, s_colT, rows, cols, st);
-  return mi::launch_mx<MI_FMT_E5M2>(x_bf16, y_row, s_row, y_colT, s_colT, rows, cols, st);
+  return MI_MX_DISPATCH(0, x_bf16, nullptr, nullptr, nullptr, rows, cols);
+}
+
+extern "C" int mi_mxfp8_norm_quantize(const void* x_bf16, const float* rstd, const void* gamma_bf16, void* y_row, void* s_row,
+                                      void* y_colT, void* s_colT, int64_t rows, int64_t cols, int fmt, void* stream) {
+  int rc = mx_common_check("mi_mxfp8_norm_quantize", x_bf16, y_row, s_row, y_colT, s_colT, rows, cols, fmt);
+  if (rc != MI_OK) return rc;
+  MI_CHECK_ARG(rstd && gamma_bf16 && ((uintptr_t)gamma_bf16 % 16) == 0, "mi_mxfp8_norm_quantize: rstd / gamma missing or misaligned");
+  if (rows == 0 || cols == 0) return MI_OK;
+  return MI_MX_DISPATCH(1, x_bf16, gamma_bf16, rstd, nullptr, rows, cols);
+}
+
+extern "C" int mi_mxfp8_swiglu_quantize(const void* h_bf16, void* y_row, void* s_row, void* y_colT, void* s_colT, int64_t rows,
+                                        int64_t F, int fmt, void* stream) {
+  int rc = mx_common_check("mi_mxfp8_swiglu_quantize", h_bf16, y_row, s_row, y_colT, s_colT, rows, F, fmt);
+  if (rc != MI_OK) return rc;
+  if (rows == 0 || F == 0) return MI_OK;
+  return MI_MX_DISPATCH(2, h_bf16, nullptr, nullptr, nullptr, rows, F);
+}
+
+extern "C" int mi_mxfp8_dswiglu_quantize(const void* h_bf16, const void* dact_bf16, void* y_row, void* s_row, void* y_colT,
+                                         void* s_colT, float* colsum, int64_t rows, int64_t F, int fmt, void* stream) {
+  int rc = mx_common_check("mi_mxfp8_dswiglu_quantize", h_bf16, y_row, s_row, y_colT, s_colT, rows, 2 * F, fmt);
+  if (rc != MI_OK) return rc;
+  MI_CHECK_ARG(dact_bf16 && ((uintptr_t)dact_bf16 % 16) == 0, "mi_mxfp8_dswiglu_quantize: dact missing or misaligned");
+  if (rows == 0 || F == 0) return MI_OK;
+  return MI_MX_DISPATCH(3, h_bf16, dact_bf16, nullptr, colsum, rows, 2 * F);
 }

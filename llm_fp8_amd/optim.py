@@ -40,14 +40,17 @@ class ClippedAdamW(torch.optim.Optimizer):
         st = torch.cuda.current_stream().cuda_stream
         coef_ptr = None
         if self.max_grad_norm is not None:
-            nblk = 256
-            need = len(items) * nblk
+            # one partial per 32 Ki elements (at most 256 per tensor): tiny tensors cost one small workgroup each
+            nblks = [max(1, min(256, (p.numel() + 32767) // 32768)) for _, p in items]
+            need = sum(nblks)
             if self._partials is None or self._partials.numel() < need or self._partials.device != dev:
                 self._partials = torch.empty(need, dtype=torch.float32, device=dev)
             part = self._partials[:need]
-            for i, (_, p) in enumerate(items):
+            off = 0
+            for (_, p), nb in zip(items, nblks):
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                _lib.check(lib.mi_sumsq_bf16(g.data_ptr(), g.numel(), part[i * nblk:].data_ptr(), nblk, st), "mi_sumsq_bf16")
+                _lib.check(lib.mi_sumsq_bf16(g.data_ptr(), g.numel(), part[off:].data_ptr(), nb, st), "mi_sumsq_bf16")
+                off += nb
             total = part.sum(dtype=torch.float32).sqrt()
             self.last_grad_norm = total
             coef = (self.max_grad_norm / (total + 1e-6)).clamp(max=1.0).reshape(1)  # clip_grad_norm_'s coefficient

@@ -96,10 +96,16 @@ class _FP8LinearFn(torch.autograd.Function):
         bias_bf16 = None if bias is None else bias.to(torch.bfloat16).contiguous()
         ctx.norm = None
         if spec.recipe.mxfp8():
-            assert ln_w is None, "fused RMSNorm is only wired for delayed scaling"
             wcat = weights[0] if len(weights) == 1 else torch.cat(list(weights), 0)
             wcat = wcat if wcat.dtype == torch.bfloat16 else wcat.to(torch.bfloat16)
-            x8, xs, xt8, xts = ops.mxfp8_quantize(x2, spec.fmt_fwd, rowwise=True, colwise=need_wgrad)
+            if ln_w is not None:
+                gam = (ln_w if ln_w.dtype == torch.bfloat16 else ln_w.to(torch.bfloat16)).contiguous()
+                rstd = ops.rmsnorm_stats(x2, spec.eps)
+                x8, xs, xt8, xts = ops.mxfp8_norm_quantize(x2, rstd, gam, spec.fmt_fwd, rowwise=True, colwise=need_wgrad)
+                if need_dgrad:
+                    ctx.norm = (x2, rstd, gam, ln_w.dtype)
+            else:
+                x8, xs, xt8, xts = ops.mxfp8_quantize(x2, spec.fmt_fwd, rowwise=True, colwise=need_wgrad)
             ck = ("mx", spec.g)
             hit = spec.wcache.get(ck) if (spec.first_mb is False and spec.wcache is not None) else None
             if hit is not None and (hit[2] is not None or not need_dgrad):
@@ -194,6 +200,11 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
         need_w = bool(ctx.needs_input_grad[1]) or bool(ctx.needs_input_grad[3])
         bwd = need_dgrad or need_w
         ctx.norm = None
+        ctx.spec, ctx.x_shape, ctx.x_dtype = spec, x.shape, x.dtype
+        ctx.dtypes = (w1.dtype, None if b1 is None else b1.dtype, w2.dtype, None if b2 is None else b2.dtype)
+        ctx.need_dgrad, ctx.need_w = need_dgrad, need_w
+        if spec.recipe.mxfp8():
+            return _FP8SwiGLUMLPFn._forward_mx(ctx, x, x2, w1, b1, w2, b2, spec, ln_w, need_dgrad, need_w, bwd)
         if ln_w is not None:  # K9: x is the un-normalised input
             gam = (ln_w if ln_w.dtype == torch.bfloat16 else ln_w.to(torch.bfloat16)).contiguous()
             rstd = ops.rmsnorm_stats(x2, spec.eps)
@@ -221,8 +232,61 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
         return y.view(*x.shape[:-1], w2.shape[0])
 
     @staticmethod
+    def _mx_weights(spec, g, w, need_t):
+        ck = ("mx", g)
+        hit = spec.wcache.get(ck) if (spec.first_mb is False and spec.wcache is not None) else None
+        if hit is not None and (hit[2] is not None or not need_t):
+            return hit
+        wb = (w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)).contiguous()
+        q = ops.mxfp8_quantize(wb, spec.fmt_fwd, rowwise=True, colwise=need_t or spec.first_mb is True)
+        if spec.first_mb is True and spec.wcache is not None:
+            spec.wcache[ck] = q
+        return q
+
+    @staticmethod
+    def _forward_mx(ctx, x, x2, w1, b1, w2, b2, spec, ln_w, need_dgrad, need_w, bwd):
+        fmt = spec.fmt_fwd
+        if ln_w is not None:
+            gam = (ln_w if ln_w.dtype == torch.bfloat16 else ln_w.to(torch.bfloat16)).contiguous()
+            rstd = ops.rmsnorm_stats(x2, spec.eps)
+            x8, xs, xt8, xts = ops.mxfp8_norm_quantize(x2, rstd, gam, fmt, rowwise=True, colwise=need_w)
+            if need_dgrad:
+                ctx.norm = (x2, rstd, gam, ln_w.dtype)
+        else:
+            x8, xs, xt8, xts = ops.mxfp8_quantize(x2, fmt, rowwise=True, colwise=need_w)
+        w1_8, w1s, w1t8, w1ts = _FP8SwiGLUMLPFn._mx_weights(spec, 0, w1, bwd)
+        h = ops.gemm_mxfp8(x8, xs, w1_8, w1s, fmt, fmt, bias=None if b1 is None else b1.to(torch.bfloat16).contiguous())
+        a8, as_, at8, ats = ops.mxfp8_swiglu_quantize(h, fmt, rowwise=True, colwise=need_w)
+        w2_8, w2s, w2t8, w2ts = _FP8SwiGLUMLPFn._mx_weights(spec, 1, w2, bwd)
+        y = ops.gemm_mxfp8(a8, as_, w2_8, w2s, fmt, fmt, bias=None if b2 is None else b2.to(torch.bfloat16).contiguous())
+        ctx.saved_fp8 = ((xt8, xts), (w1t8, w1ts), (at8, ats), (w2t8, w2ts), h if bwd else None, None)
+        return y.view(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def _backward_mx(ctx, dy):
+        spec = ctx.spec
+        fmt_f, fmt_b = spec.fmt_fwd, spec.fmt_bwd
+        (xt8, xts), (w1t8, w1ts), (at8, ats), (w2t8, w2ts), h, _ = ctx.saved_fp8
+        ctx.saved_fp8 = None
+        g2 = _as_bf16_2d(dy)
+        g8, gs, gt8, gts = ops.mxfp8_quantize(g2, fmt_b, rowwise=True, colwise=ctx.need_w)
+        dact = ops.gemm_mxfp8(g8, gs, w2t8, w2ts, fmt_b, fmt_f)
+        dw2 = ops.gemm_mxfp8(gt8, gts, at8, ats, fmt_b, fmt_f) if ctx.need_w else None
+        db2 = g2.sum(0, dtype=torch.float32).to(ctx.dtypes[3]) if ctx.dtypes[3] is not None else None
+        want_b1 = ctx.dtypes[1] is not None
+        dh8, dhs, dht8, dhts, colsum = ops.mxfp8_dswiglu_quantize(h, dact, fmt_b, rowwise=ctx.need_dgrad, colwise=ctx.need_w,
+                                                                  want_colsum=want_b1)
+        db1 = colsum.sum(0).to(ctx.dtypes[1]) if want_b1 else None
+        dx = ops.gemm_mxfp8(dh8, dhs, w1t8, w1ts, fmt_b, fmt_f) if ctx.need_dgrad else None
+        dw1 = ops.gemm_mxfp8(dht8, dhts, xt8, xts, fmt_b, fmt_f) if ctx.need_w else None
+        return dx, dw1, db1, dw2, db2
+
+    @staticmethod
     def backward(ctx, dy):
         spec = ctx.spec
+        if spec.recipe.mxfp8():
+            dx, dw1, db1, dw2, db2 = _FP8SwiGLUMLPFn._backward_mx(ctx, dy)
+            return _FP8SwiGLUMLPFn._finish_backward(ctx, dx, dw1, db1, dw2, db2)
         mb, fmt_f, fmt_b = spec.meta_bwd, spec.fmt_fwd, spec.fmt_bwd
         x8t, w1_8t, a8t, w2_8t, h, sinv = ctx.saved_fp8
         ctx.saved_fp8 = None
@@ -239,6 +303,11 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
         db1 = colsum.sum(0).to(ctx.dtypes[1]) if want_b1 else None
         dx = ops.gemm_fp8(dh8, w1_8t, mb.scale_inv(0), sinv[1:2], fmt_b, fmt_f) if ctx.need_dgrad else None
         dw1 = ops.gemm_fp8(dh8t, x8t, mb.scale_inv(0), sinv[0:1], fmt_b, fmt_f) if ctx.need_w else None
+        return _FP8SwiGLUMLPFn._finish_backward(ctx, dx, dw1, db1, dw2, db2)
+
+    @staticmethod
+    def _finish_backward(ctx, dx, dw1, db1, dw2, db2):
+        spec = ctx.spec
         dln = None
         if ctx.norm is not None and dx is not None:
             xin, rstd, gam, ln_dtype = ctx.norm
@@ -454,10 +523,10 @@ class LayerNormLinear(_FP8Module):
 
 
 def _can_fuse_norm(mod, recipe, inp) -> bool:
-    """K9 applies to RMSNorm under delayed scaling; the backward kernel keeps a whole row per wave (cols % 512, <= 8192)."""
+    """K9 applies to RMSNorm (delayed scaling and MXFP8); the backward kernel keeps a whole row per wave (cols % 512, <= 8192)."""
     h = inp.shape[-1]
     return (getattr(mod, "fused_norm", True) and mod.normalization == "RMSNorm" and not mod.zero_centered_gamma
-            and recipe.delayed() and h % 512 == 0 and h // 512 in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16))
+            and (recipe.delayed() or recipe.mxfp8()) and h % 512 == 0 and h // 512 in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16))
 
 
 def _swiglu(a: torch.Tensor) -> torch.Tensor:
@@ -517,7 +586,7 @@ class LayerNormMLP(_FP8Module):
             return F.linear(self.act_fn(h), self.fc2_weight.to(ln.dtype),
                             None if self.fc2_bias is None else self.fc2_bias.to(ln.dtype))
         recipe, mf, mb, first = st
-        if self.activation == "swiglu" and recipe.delayed() and self.fused_swiglu:
+        if self.activation == "swiglu" and self.fused_swiglu and (recipe.delayed() or inp.numel() // inp.shape[-1] % 32 == 0):
             return _FP8SwiGLUMLPFn.apply(ln, self.fc1_weight, self.fc1_bias, self.fc2_weight, self.fc2_bias,
                                          _GemmSpec(recipe, mf, mb, 0, first, self.training, wcache=self._wcache,
                                                    first_mb=is_first_microbatch))

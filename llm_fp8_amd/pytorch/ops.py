@@ -280,3 +280,64 @@ def rmsnorm_bwd(dy: torch.Tensor, x: torch.Tensor, rstd: torch.Tensor, gamma: to
                                     part.data_ptr(), n_partials, R, C, _stream())
     _lib.check(rc, "mi_rmsnorm_bwd")
     return dx, part.sum(0)
+
+
+def _mx_alloc(R: int, C: int, dev, rowwise: bool, colwise: bool):
+    y_row = s_row = y_colT = s_colT = None
+    if rowwise:
+        y_row = torch.empty((R, C), dtype=torch.uint8, device=dev)
+        s_row = torch.empty((C // 32, R), dtype=torch.uint8, device=dev)
+    if colwise:
+        y_colT = torch.empty((C, R), dtype=torch.uint8, device=dev)
+        s_colT = torch.empty((R // 32, C), dtype=torch.uint8, device=dev)
+    return y_row, s_row, y_colT, s_colT
+
+
+def _mx_call(kind: str, fn, args, R: int, C: int, in_bytes: float, rowwise: bool, colwise: bool):
+    t = KernelTimer.active
+    if t is None:
+        rc = fn(*args)
+    else:
+        with t.span("mxfp8_quantize", f"{kind} {R}x{C}", float(R * C), in_bytes + R * C * (1 + 1 / 32) * (int(rowwise) + int(colwise))):
+            rc = fn(*args)
+    _lib.check(rc, f"mi_mxfp8_{kind}_quantize")
+
+
+def mxfp8_norm_quantize(x: torch.Tensor, rstd: torch.Tensor, gamma: torch.Tensor, fmt: int = E4M3, rowwise: bool = True,
+                        colwise: bool = True):
+    """K9 for MXFP8: quantises (x * rstd[:, None]) * gamma without materialising it.  Same outputs as mxfp8_quantize."""
+    _dev(x, rstd, gamma)
+    assert x.dtype == torch.bfloat16 and gamma.dtype == torch.bfloat16 and x.is_contiguous() and gamma.is_contiguous()
+    R, C = x.shape
+    out = _mx_alloc(R, C, x.device, rowwise, colwise)
+    _mx_call("norm", _lib.load().mi_mxfp8_norm_quantize,
+             (x.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), *[_ptr(o) for o in out], R, C, fmt, _stream()), R, C, 2.0 * R * C,
+             rowwise, colwise)
+    return out
+
+
+def mxfp8_swiglu_quantize(h: torch.Tensor, fmt: int = E4M3, rowwise: bool = True, colwise: bool = True):
+    """K10 for MXFP8: quantises silu(h[:, :F]) * h[:, F:] ([R, F])."""
+    _dev(h)
+    assert h.dtype == torch.bfloat16 and h.is_contiguous() and h.shape[1] % 2 == 0
+    R, F = h.shape[0], h.shape[1] // 2
+    out = _mx_alloc(R, F, h.device, rowwise, colwise)
+    _mx_call("swiglu", _lib.load().mi_mxfp8_swiglu_quantize, (h.data_ptr(), *[_ptr(o) for o in out], R, F, fmt, _stream()), R, F,
+             4.0 * R * F, rowwise, colwise)
+    return out
+
+
+def mxfp8_dswiglu_quantize(h: torch.Tensor, dact: torch.Tensor, fmt: int = E4M3, rowwise: bool = True, colwise: bool = True,
+                           want_colsum: bool = False):
+    """K10 backward for MXFP8: quantises dh = [dact*dsilu(g)*u | dact*silu(g)] ([R, 2F]); returns (..., colsum or None)."""
+    _dev(h, dact)
+    assert h.dtype == torch.bfloat16 and dact.dtype == torch.bfloat16 and h.is_contiguous() and dact.is_contiguous()
+    R, F2 = h.shape
+    F = F2 // 2
+    assert dact.shape == (R, F)
+    out = _mx_alloc(R, F2, h.device, rowwise, colwise)
+    cs = torch.empty(((R + 127) // 128, F2), dtype=torch.float32, device=h.device) if want_colsum else None
+    _mx_call("dswiglu", _lib.load().mi_mxfp8_dswiglu_quantize,
+             (h.data_ptr(), dact.data_ptr(), *[_ptr(o) for o in out], _ptr(cs), R, F, fmt, _stream()), R, F2, 6.0 * R * F,
+             rowwise, colwise)
+    return (*out, cs)

@@ -194,11 +194,13 @@ def main(argv=None):
     ap.add_argument("--learning_rate", type=float, default=1.41e-5)
     ap.add_argument("--num_hidden_layers", type=int, default=None)
     ap.add_argument("--vocab_size", type=int, default=None)
+    ap.add_argument("--num_warmup_steps", type=int, default=100)
+    ap.add_argument("--repeat_batch", action="store_true", help="debug: train on one fixed synthetic batch")
     a = ap.parse_args(argv)
     cfg = TrainingConfig(model_name=a.model_name, batch_size=a.batch_size, max_seq_length=a.max_seq_length,
                          mixed_precision=a.mixed_precision, fp8_scenario=a.fp8_scenario, use_te=a.use_te,
                          sharding_mode=a.sharding_mode, learning_rate=a.learning_rate,
-                         num_hidden_layers=a.num_hidden_layers, vocab_size=a.vocab_size)
+                         num_hidden_layers=a.num_hidden_layers, vocab_size=a.vocab_size, num_warmup_steps=a.num_warmup_steps)
     rank, local, world, device = setup_distributed()
     torch.manual_seed(cfg.seed + rank)
     model = prepare_model(create_model(cfg, device), cfg)
@@ -206,9 +208,10 @@ def main(argv=None):
     model = wrap_distributed(model, cfg, device)
     opt, sched = create_optimizer(model, cfg)
     model.train()
+    fixed = synthetic_batch(cfg, vocab, device) if a.repeat_batch else None
     for step in range(a.num_steps):
         t0 = time.perf_counter()
-        loss = train_step(model, synthetic_batch(cfg, vocab, device), opt, sched, cfg)
+        loss = train_step(model, fixed if fixed is not None else synthetic_batch(cfg, vocab, device), opt, sched, cfg)
         lv = loss.item()
         if not math.isfinite(lv):
             print("Non-finite loss detected, stopping training.")

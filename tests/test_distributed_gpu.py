@@ -18,7 +18,8 @@ def test_train_harness_under_wrappers_world1(dev, mode, scenario):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29531", "-m", "llm_fp8_amd.train", "--model_name", "llama-3.2-1b", "--num_hidden_layers", "2",
            "--vocab_size", "4096", "--batch_size", "4", "--max_seq_length", "128", "--mixed_precision", "fp8", "--use_te",
-           "--fp8_scenario", scenario, "--sharding_mode", mode, "--num_steps", "4", "--learning_rate", "1e-3"]
+           "--fp8_scenario", scenario, "--sharding_mode", mode, "--num_steps", "4", "--learning_rate", "1e-3",
+           "--num_warmup_steps", "0", "--repeat_batch"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]

@@ -285,6 +285,32 @@ def test_train_steps_run_and_update_once_per_step(te, dev, use_te, scenario):
     assert torch.isfinite(out.loss)
 
 
+def test_fused_mx_mlp_matches_unfused(te, dev):
+    """MXFP8: fused norm/SwiGLU quantisers vs the unfused module path (torch rms_norm / silu*mul then plain quantise)."""
+    _, Format, MXFP8BlockScaling = _recipes()
+    recipe = MXFP8BlockScaling(fp8_format=Format.E4M3)
+    h, f = 512, 1024
+    torch.manual_seed(12)
+    a = te.LayerNormMLP(h, f, normalization="RMSNorm", activation="swiglu", params_dtype=torch.bfloat16, device=dev)
+    b = te.LayerNormMLP(h, f, normalization="RMSNorm", activation="swiglu", params_dtype=torch.bfloat16, device=dev)
+    with torch.no_grad():
+        a.fc1_bias.normal_(0, 0.1); a.fc2_bias.normal_(0, 0.1); a.layer_norm_weight.copy_(torch.linspace(0.5, 1.5, h))
+    b.load_state_dict(a.state_dict())
+    b.fused_swiglu = False
+    b.fused_norm = False
+    x = torch.randn(2, 64, h, device=dev, dtype=torch.bfloat16)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    with te.fp8_autocast(enabled=True, fp8_recipe=recipe):
+        ya, yb = a(xa), b(xb)
+    gy = torch.randn_like(ya) / 16
+    ya.backward(gy); yb.backward(gy)
+    for got, ref, name in ((ya, yb, "y"), (xa.grad, xb.grad, "dx"), (a.fc1_weight.grad, b.fc1_weight.grad, "dw1"),
+                           (a.fc2_weight.grad, b.fc2_weight.grad, "dw2"), (a.fc1_bias.grad, b.fc1_bias.grad, "db1"),
+                           (a.layer_norm_weight.grad, b.layer_norm_weight.grad, "dgamma")):
+        rel = (got.float() - ref.float()).norm() / ref.float().norm()
+        assert rel < 0.05, f"{name}: rel {rel:.4f}"  # two FP8 quantisations of values that differ by a bf16 rounding
+
+
 def test_fused_swiglu_mlp_matches_unfused(te, dev):
     """K10 fusion (SwiGLU + cast in one kernel, bf16 activation never materialised) vs the two-Linear path:
     same scales and amaxes up to the bf16 rounding of the activation the unfused path inserts."""
