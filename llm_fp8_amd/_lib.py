@@ -37,6 +37,8 @@ SIGNATURES = {
     "mi_sumsq_bf16": [_p, _c_i64, _p, _c_int, _p],
     "mi_adamw_bf16": [_p, _p, _p, _p, _c_i64, _p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                       ctypes.c_float, _c_i64, _p],
+    "mi_attn_fwd": [_p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_i64, ctypes.c_float,
+                    _c_int, _p],
     "mi_mxfp8_norm_quantize": [_p, _p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],
     "mi_mxfp8_swiglu_quantize": [_p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],
     "mi_mxfp8_dswiglu_quantize": [_p, _p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],

@@ -1,0 +1,237 @@
+// Attention core of te.pytorch.MultiheadAttention (te_llama.py:45-56,77: causal, GQA, bshd, no dropout) as flash-style
+// bf16 kernels for gfx950: S = QK^T never leaves the register file.
+//
+//   attn_fwd_kernel   one workgroup = 4 waves = 128 query rows of one (batch, head); each wave keeps its 32 query rows as
+//                     the B operand of  S^T = K . Q^T  (v_mfma_f32_32x32x16_bf16), so a lane holds 2 x 16 scores of ONE
+//                     query row: the online-softmax state (m, l) and the rescale of O^T are lane-local.  The S^T
+//                     accumulators, converted pairwise to bf16, are directly the B operand of  O^T += V^T . P^T ; the
+//                     V^T fragments come from the row-major V tile with ds_read_b64_tr_b16.  K/V tiles of 64 keys are
+//                     register-staged into a double-buffered, XOR-swizzled LDS image; one barrier per tile.
+//   attn_bwd_dq_kernel / attn_bwd_dkdv_kernel   recompute P from the stored log-sum-exp (no S x S tensor); dQ and
+//                     dK/dV are separate passes so that no sum crosses workgroups (bitwise reproducible, no atomics).
+//
+// Layouts: q/o [B, S, H, D], k/v [B, S, G, D] bf16 with D contiguous and a caller-given token stride; lse [B, H, S] f32 in
+// the log2 domain (m * c + log2 l, c = scale * log2 e).
+#include "mi_common.h"
+
+namespace mi {
+
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef short s8v __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) s4v lds_s4v;
+
+// byte offset of 16-byte chunk `ch` of row `row` in a [rows][D] bf16 tile image; the XOR keeps both the ds_read_b128 row
+// reads and the ds_read_b64_tr_b16 transposed reads of the 32x32x16 operands spread over the banks
+template <int D>
+__device__ __forceinline__ int tile_off(int row, int ch) {
+  if (D == 128) return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+  return 128 * row + 16 * (ch ^ (((row & 1) << 2) | ((row >> 1) & 3)));
+}
+
+__device__ __forceinline__ bf8 as_bf8(v4i v) { return __builtin_bit_cast(bf8, v); }
+
+// row fragment of the 32x32x16 A/B operand: lane (r, h) <- row r0 + r, elements [16 t + 8 h, +8)
+template <int D>
+__device__ __forceinline__ bf8 row_frag(const char* tile, int r0, int t, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  return as_bf8(*reinterpret_cast<const v4i*>(tile + tile_off<D>(r0 + r, 2 * t + h)));
+}
+
+// transposed fragment: lane (c = lane & 31, h) <- column c0 + c, rows {rb, rb+1, rb+2, rb+3, rb+8, .., rb+11}, rb = r0 + 4 h:
+// exactly the row set a 32x32 accumulator keeps in registers 8 s .. 8 s + 7 (r0 = 16 s)
+template <int D>
+__device__ __forceinline__ bf8 tr_frag(const char* tile, int r0, int c0, int lane) {
+  const int i16 = lane & 15, qq = i16 >> 2, pp = i16 & 3, half = (lane >> 4) & 1, h = lane >> 5;
+  const int ch = (c0 >> 3) + 2 * half + (pp >> 1);
+  const int rb = r0 + 4 * h + qq;
+  const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(tile + tile_off<D>(rb, ch) + 8 * (pp & 1)));
+  const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(tile + tile_off<D>(rb + 8, ch) + 8 * (pp & 1)));
+  s8v v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return __builtin_bit_cast(bf8, v);
+}
+
+// accumulator registers 8 s .. 8 s + 7 -> bf16 fragment (B operand of a product that sums over the accumulator's rows)
+__device__ __forceinline__ bf8 acc_frag(const f16v& a, int s) {
+  v4i v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = (int)pack_bf16x2(a[8 * s + 2 * j], a[8 * s + 2 * j + 1]);
+  return as_bf8(v);
+}
+
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+constexpr int ATT_QB = 128;  // query rows per workgroup (4 waves x 32)
+constexpr int ATT_KB = 64;   // keys per tile
+
+template <int D>
+__device__ __forceinline__ void stage_load(v4i (&reg)[D / 32], const uint16_t* base, int64_t tok_stride, int tid) {
+#pragma unroll
+  for (int i = 0; i < D / 32; ++i) {
+    const int c = tid + 256 * i, row = c / (D / 8), ch = c % (D / 8);
+    reg[i] = *reinterpret_cast<const v4i*>(base + (int64_t)row * tok_stride + ch * 8);
+  }
+}
+template <int D>
+__device__ __forceinline__ void stage_store(const v4i (&reg)[D / 32], char* tile, int tid) {
+#pragma unroll
+  for (int i = 0; i < D / 32; ++i) {
+    const int c = tid + 256 * i, row = c / (D / 8), ch = c % (D / 8);
+    *reinterpret_cast<v4i*>(tile + tile_off<D>(row, ch)) = reg[i];
+  }
+}
+
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+                                                          const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
+                                                          float* __restrict__ lse, int S, int H, int G, int64_t q_ts,
+                                                          int64_t k_ts, int64_t v_ts, int64_t o_ts, float c) {
+  constexpr int TILE = ATT_KB * D * 2;  // bytes of one K (or V) tile
+  constexpr int KT = D / 16, DB = D / 32;
+  __shared__ __attribute__((aligned(16))) char lds[4 * TILE];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int qb = gridDim.x - 1 - blockIdx.x, head = blockIdx.y, b = blockIdx.z, g = head / (H / G);
+  const int q_first = qb * ATT_QB + w * 32;  // first query row of this wave
+  const int qrow = q_first + r;
+  const int ntiles = CAUSAL ? (qb * ATT_QB + ATT_QB) / ATT_KB : S / ATT_KB;
+  const uint16_t* kbase = k + (int64_t)b * S * k_ts + (int64_t)g * D;
+  const uint16_t* vbase = v + (int64_t)b * S * v_ts + (int64_t)g * D;
+
+  bf8 qf[KT];
+  {
+    const uint16_t* qp = q + ((int64_t)b * S + qrow) * q_ts + (int64_t)head * D + 8 * h;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) qf[t] = as_bf8(*reinterpret_cast<const v4i*>(qp + 16 * t));
+  }
+  f16v oacc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) oacc[d][i] = 0.0f;
+  float m = -1.0e30f, l = 0.0f;
+
+  v4i kreg[D / 32], vreg[D / 32];
+  stage_load<D>(kreg, kbase, k_ts, tid);
+  stage_load<D>(vreg, vbase, v_ts, tid);
+  stage_store<D>(kreg, lds, tid);
+  stage_store<D>(vreg, lds + 2 * TILE, tid);
+  __syncthreads();
+
+  for (int j = 0; j < ntiles; ++j) {
+    const char* kt = lds + (j & 1) * TILE;
+    const char* vt = lds + (2 + (j & 1)) * TILE;
+    const bool more = j + 1 < ntiles;
+    if (more) {
+      stage_load<D>(kreg, kbase + (int64_t)(j + 1) * ATT_KB * k_ts, k_ts, tid);
+      stage_load<D>(vreg, vbase + (int64_t)(j + 1) * ATT_KB * v_ts, v_ts, tid);
+    }
+    const int key0 = j * ATT_KB;
+    if (!CAUSAL || key0 <= q_first + 31) {  // wave-uniform: tiles entirely above the diagonal contribute nothing
+      f16v sacc[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(kt, 32 * kb, t, lane), qf[t], sacc[kb], 0, 0, 0);
+      }
+      if (CAUSAL && key0 + ATT_KB - 1 > q_first) {  // tile touches the diagonal
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (key0 + 32 * kb + acc_row(i, h) > qrow) sacc[kb][i] = -INFINITY;
+      }
+      float mx = sacc[0][0];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sacc[kb][i]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c);
+      const float mc = m_new * c;
+      m = m_new;
+      float psum = 0.0f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kb][i], c, -mc));
+          sacc[kb][i] = p;
+          psum += p;
+        }
+      l = l * alpha + psum;
+#pragma unroll
+      for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const bf8 pf = acc_frag(sacc[kb], s);
+#pragma unroll
+          for (int d = 0; d < DB; ++d)
+            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(vt, 32 * kb + 16 * s, 32 * d, lane), pf, oacc[d], 0, 0, 0);
+        }
+    }
+    if (more) {
+      stage_store<D>(kreg, lds + ((j + 1) & 1) * TILE, tid);
+      stage_store<D>(vreg, lds + (2 + ((j + 1) & 1)) * TILE, tid);
+    }
+    __syncthreads();
+  }
+
+  l += __shfl_xor(l, 32);
+  const float inv = 1.0f / l;
+  if (h == 0) lse[((int64_t)b * H + head) * S + qrow] = m * c + __builtin_amdgcn_logf(l);  // v_log_f32 = log2
+  // O^T (d in registers, query on the lane) -> whole rows through this wave's own LDS slice
+  char* ot = lds + w * (32 * D * 2);
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = 4 * d + i;
+      uint2 pk;
+      pk.x = pack_bf16x2(oacc[d][4 * i] * inv, oacc[d][4 * i + 1] * inv);
+      pk.y = pack_bf16x2(oacc[d][4 * i + 2] * inv, oacc[d][4 * i + 3] * inv);
+      *reinterpret_cast<uint2*>(ot + r * (D * 2) + 16 * (ch ^ (r & (D / 8 - 1))) + 8 * h) = pk;
+    }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the slice is private to the wave, no barrier needed
+  __builtin_amdgcn_wave_barrier();
+  constexpr int CPR = D / 8;  // 16-byte chunks per row
+#pragma unroll
+  for (int it = 0; it < 32 * CPR / 64; ++it) {
+    const int idx = it * 64 + lane, row = idx / CPR, ch = idx % CPR;
+    const v4i val = *reinterpret_cast<const v4i*>(ot + row * (D * 2) + 16 * (ch ^ (row & (CPR - 1))));
+    *reinterpret_cast<v4i*>(o + ((int64_t)b * S + q_first + row) * o_ts + (int64_t)head * D + ch * 8) = val;
+  }
+}
+
+}  // namespace mi
+
+extern "C" int mi_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int S, int H, int G,
+                           int D, int64_t q_ts, int64_t k_ts, int64_t v_ts, int64_t o_ts, float scale, int causal,
+                           void* stream) {
+  MI_CHECK_ARG(q && k && v && o && lse, "mi_attn_fwd: null pointer");
+  MI_CHECK_ARG(B >= 1 && H >= 1 && G >= 1 && H % G == 0, "mi_attn_fwd: bad B/H/G (%d, %d, %d)", B, H, G);
+  MI_CHECK_ARG(D == 128, "mi_attn_fwd: head_dim %d not supported (128)", D);
+  MI_CHECK_ARG(S >= 128 && S % 128 == 0, "mi_attn_fwd: seq %d must be a multiple of 128", S);
+  MI_CHECK_ARG(q_ts % 8 == 0 && k_ts % 8 == 0 && v_ts % 8 == 0 && o_ts % 8 == 0, "mi_attn_fwd: token strides must be multiples of 8");
+  MI_CHECK_ARG(H <= 65535 && B <= 65535, "mi_attn_fwd: grid too large");
+  const float c = scale * 1.4426950408889634f;
+  dim3 grid(S / mi::ATT_QB, H, B), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (causal)
+    hipLaunchKernelGGL((mi::attn_fwd_kernel<128, true>), grid, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,
+                       (const uint16_t*)v, (uint16_t*)o, lse, S, H, G, q_ts, k_ts, v_ts, o_ts, c);
+  else
+    hipLaunchKernelGGL((mi::attn_fwd_kernel<128, false>), grid, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,
+                       (const uint16_t*)v, (uint16_t*)o, lse, S, H, G, q_ts, k_ts, v_ts, o_ts, c);
+  MI_CHECK_LAUNCH("mi_attn_fwd launch");
+  return MI_OK;
+}

@@ -14,15 +14,33 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const uint16_t* __restrict__
   const int64_t nvec = n >> 3;
   const bool aligned = ((uintptr_t)g & 15) == 0;
   if (aligned) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < nvec; i += (int64_t)gridDim.x * 256) {
+    // four independent 16-byte loads in flight per lane and iteration (the pass is latency-bound otherwise)
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    float acc4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int64_t i = (int64_t)blockIdx.x * 256 + tid;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+      v4i v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(g) + i + u * stride);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const u32 w = (u32)v[u][j];
+          const float a = __uint_as_float(w << 16), b = __uint_as_float(w & 0xFFFF0000u);
+          acc4[u] += a * a + b * b;
+        }
+    }
+    for (; i < nvec; i += stride) {
       const v4i v = reinterpret_cast<const v4i*>(g)[i];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const u32 w = (u32)v[j];
         const float a = __uint_as_float(w << 16), b = __uint_as_float(w & 0xFFFF0000u);
-        acc += a * a + b * b;
+        acc4[0] += a * a + b * b;
       }
     }
+    acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
     for (int64_t i = (nvec << 3) + (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
       const float a = bf16_bits_to_float(g[i]);
       acc += a * a;

@@ -40,8 +40,8 @@ class ClippedAdamW(torch.optim.Optimizer):
         st = torch.cuda.current_stream().cuda_stream
         coef_ptr = None
         if self.max_grad_norm is not None:
-            # one partial per 32 Ki elements (at most 256 per tensor): tiny tensors cost one small workgroup each
-            nblks = [max(1, min(256, (p.numel() + 32767) // 32768)) for _, p in items]
+            # one partial per 8 Ki elements (at most 2048 per tensor, 8 workgroups per CU): tiny tensors cost one workgroup
+            nblks = [max(1, min(2048, (p.numel() + 8191) // 8192)) for _, p in items]
             need = sum(nblks)
             if self._partials is None or self._partials.numel() < need or self._partials.device != dev:
                 self._partials = torch.empty(need, dtype=torch.float32, device=dev)

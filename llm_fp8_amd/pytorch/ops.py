@@ -341,3 +341,30 @@ def mxfp8_dswiglu_quantize(h: torch.Tensor, dact: torch.Tensor, fmt: int = E4M3,
              (h.data_ptr(), dact.data_ptr(), *[_ptr(o) for o in out], _ptr(cs), R, F, fmt, _stream()), R, F2, 6.0 * R * F,
              rowwise, colwise)
     return (*out, cs)
+
+
+def _bshd_ok(t: torch.Tensor, D: int):
+    assert t.dtype == torch.bfloat16 and t.dim() == 4 and t.shape[3] == D and t.stride(3) == 1 and t.stride(2) == D
+    assert t.stride(0) == t.shape[1] * t.stride(1), "batch and sequence must collapse to one token stride"
+
+
+def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, causal: bool = True):
+    """Attention core.  q [B, S, H, D], k/v [B, S, G, D] bf16 (views with a token stride are fine) -> (o [B, S, H, D], lse [B, H, S])."""
+    _dev(q, k, v)
+    B, S, H, D = q.shape
+    G = k.shape[2]
+    for t in (q, k, v):
+        _bshd_ok(t, D)
+    o = torch.empty((B, S, H, D), dtype=torch.bfloat16, device=q.device)
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
+    args = (q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, S, H, G, D, q.stride(1), k.stride(1),
+            v.stride(1), o.stride(1), float(scale), int(causal), _stream())
+    t = KernelTimer.active
+    flops = 4.0 * B * H * S * S * D * (0.5 if causal else 1.0)
+    if t is None:
+        rc = _lib.load().mi_attn_fwd(*args)
+    else:
+        with t.span("attn_fwd", f"{B}x{S}x{H}x{D}", flops, 2.0 * (q.numel() * 2 + k.numel() * 2)):
+            rc = _lib.load().mi_attn_fwd(*args)
+    _lib.check(rc, "mi_attn_fwd")
+    return o, lse

@@ -400,3 +400,54 @@ def rmsnorm_bwd_f32(dy_bits: np.ndarray, x_bits: np.ndarray, gamma_bits: np.ndar
     c = (wdy * xh).mean(axis=1)
     dx = rstd[:, None] * (wdy - xh * c[:, None])
     return dx.astype(np.float32), (dy * xh).sum(axis=0).astype(np.float32)
+
+
+def attention_f64(q_bits, k_bits, v_bits, scale: float, causal: bool = True):
+    """Attention core (te_llama.py:45-56: causal, GQA): q [B,S,H,D], k/v [B,S,G,D] bf16 bits -> (o f32 [B,S,H,D], lse_log2 [B,H,S]).
+    float64 math; lse in the log2 domain of the scaled scores (the layout the HIP kernel keeps for its backward)."""
+    q = bf16_bits_to_f32(q_bits).astype(np.float64)
+    k = bf16_bits_to_f32(k_bits).astype(np.float64)
+    v = bf16_bits_to_f32(v_bits).astype(np.float64)
+    B, S, H, D = q.shape
+    G = k.shape[2]
+    rep = H // G
+    o = np.zeros((B, S, H, D))
+    lse = np.zeros((B, H, S))
+    mask = np.triu(np.ones((S, S), dtype=bool), 1)
+    for h in range(H):
+        g = h // rep
+        s = np.einsum("bqd,bkd->bqk", q[:, :, h], k[:, :, g]) * scale
+        if causal:
+            s = np.where(mask[None], -np.inf, s)
+        m = s.max(-1, keepdims=True)
+        p = np.exp(s - m)
+        l = p.sum(-1, keepdims=True)
+        o[:, :, h] = np.einsum("bqk,bkd->bqd", p / l, v[:, :, g])
+        lse[:, h] = (m[..., 0] + np.log(l[..., 0])) / np.log(2.0)
+    return o.astype(np.float32), lse.astype(np.float32)
+
+
+def attention_bwd_f64(q_bits, k_bits, v_bits, do_bits, scale: float, causal: bool = True):
+    """(dq, dk, dv) float32 of attention_f64's o w.r.t. its inputs, given dO (bf16 bits)."""
+    q = bf16_bits_to_f32(q_bits).astype(np.float64)
+    k = bf16_bits_to_f32(k_bits).astype(np.float64)
+    v = bf16_bits_to_f32(v_bits).astype(np.float64)
+    do = bf16_bits_to_f32(do_bits).astype(np.float64)
+    B, S, H, D = q.shape
+    G = k.shape[2]
+    rep = H // G
+    dq, dk, dv = np.zeros_like(q), np.zeros_like(k), np.zeros_like(v)
+    mask = np.triu(np.ones((S, S), dtype=bool), 1)
+    for h in range(H):
+        g = h // rep
+        s = np.einsum("bqd,bkd->bqk", q[:, :, h], k[:, :, g]) * scale
+        if causal:
+            s = np.where(mask[None], -np.inf, s)
+        p = np.exp(s - s.max(-1, keepdims=True))
+        p /= p.sum(-1, keepdims=True)
+        dv[:, :, g] += np.einsum("bqk,bqd->bkd", p, do[:, :, h])
+        dp = np.einsum("bqd,bkd->bqk", do[:, :, h], v[:, :, g])
+        ds = p * (dp - (p * dp).sum(-1, keepdims=True)) * scale
+        dq[:, :, h] = np.einsum("bqk,bkd->bqd", ds, k[:, :, g])
+        dk[:, :, g] += np.einsum("bqk,bqd->bkd", ds, q[:, :, h])
+    return dq.astype(np.float32), dk.astype(np.float32), dv.astype(np.float32)

@@ -443,3 +443,48 @@ def test_mxfp8_fused_front_ends_vs_oracle(ops, dev, shape):
     dh = O.dswiglu_f32(bf16_bits(h), bf16_bits(d))
     check(out[:4], dh, "dswiglu")
     np.testing.assert_allclose(out[4].sum(0).cpu().numpy(), dh.astype(np.float64).sum(0), rtol=1e-4, atol=1e-4 * np.abs(dh).max() * np.sqrt(R))
+
+
+def _torch_attn_ref(q, k, v, scale, causal=True):
+    """fp32 torch reference of the attention core on the device (full sizes); q [B,S,H,D], k/v [B,S,G,D]."""
+    B, S, H, D = q.shape
+    G = k.shape[2]
+    qf, kf, vf = (t.float().transpose(1, 2) for t in (q, k, v))
+    kf, vf = kf.repeat_interleave(H // G, 1), vf.repeat_interleave(H // G, 1)
+    s = (qf @ kf.transpose(-1, -2)) * scale
+    if causal:
+        s = s.masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool, device=q.device), 1), float("-inf"))
+    lse2 = torch.logsumexp(s, -1) / np.log(2.0)
+    return (torch.softmax(s, -1) @ vf).transpose(1, 2), lse2
+
+
+@pytest.mark.parametrize("B,S,H,G", [(1, 128, 2, 1), (2, 256, 6, 2), (1, 512, 3, 3)])
+@pytest.mark.parametrize("causal", [True, False])
+def test_attn_fwd_vs_oracle(ops, dev, B, S, H, G, causal):
+    D = 128
+    g = torch.Generator().manual_seed(S + H)
+    q, k, v = (torch.randn(B, S, n, D, generator=g).to(torch.bfloat16) for n in (H, G, G))
+    q = q * 2.0  # sharper softmax
+    scale = D ** -0.5
+    o_ref, lse_ref = O.attention_f64(bf16_bits(q), bf16_bits(k), bf16_bits(v), scale, causal)
+    o, lse = ops.attn_fwd(q.to(dev), k.to(dev), v.to(dev), scale, causal)
+    # P is rounded to bf16 before P.V and O to bf16 at the end: 2^-8 relative each, on values bounded by max|v|
+    np.testing.assert_allclose(o.float().cpu().numpy(), o_ref, rtol=2 ** -6, atol=2 ** -7 * float(v.abs().max()))
+    np.testing.assert_allclose(lse.cpu().numpy(), lse_ref, rtol=0, atol=2e-3)
+
+
+def test_attn_fwd_strided_views_and_full_size(ops, dev):
+    """Operands as column slices of one fused [tokens, (H + 2G) D] buffer, BASELINE config sizes (3B: B16 S512 H24 G8 D128)."""
+    B, S, H, G, D = 16, 512, 24, 8, 128
+    g = torch.Generator(device=dev).manual_seed(1)
+    qkv = torch.randn(B, S, (H + 2 * G) * D, device=dev, dtype=torch.bfloat16, generator=g)
+    q = qkv[..., :H * D].view(B, S, H, D)
+    k = qkv[..., H * D:(H + G) * D].view(B, S, G, D)
+    v = qkv[..., (H + G) * D:].view(B, S, G, D)
+    scale = D ** -0.5
+    o, lse = ops.attn_fwd(q, k, v, scale, True)
+    o_ref, lse_ref = _torch_attn_ref(q, k, v, scale, True)
+    assert torch.isfinite(o).all()
+    err = (o.float() - o_ref).abs().max().item()
+    assert err < 2 ** -6 * float(v.abs().max()), err
+    assert (lse - lse_ref).abs().max().item() < 2e-3
