@@ -204,6 +204,15 @@ int mi_adamw_bf16(void* p_bf16, const void* g_bf16, void* exp_avg_bf16, void* ex
  */
 int mi_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int S, int H, int G, int D,
                 int64_t q_ts, int64_t k_ts, int64_t v_ts, int64_t o_ts, float scale, int causal, void* stream);
+/*
+ * Backward of mi_attn_fwd: P is recomputed from q, k and `lse`; two launches (dQ pass, which also writes
+ * delta[B, H, S] = rowsum(dO * O), then the dK/dV pass), no sums across workgroups: results are bitwise reproducible.
+ * dq [B, S, H, D], dk / dv [B, S, G, D] bf16 with their own token strides (they may be slices of one fused buffer).
+ */
+int mi_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                float* delta, void* dq, void* dk, void* dv, int B, int S, int H, int G, int D, int64_t q_ts,
+                int64_t k_ts, int64_t v_ts, int64_t o_ts, int64_t do_ts, int64_t dq_ts, int64_t dk_ts, int64_t dv_ts,
+                float scale, int causal, void* stream);
 
 #ifdef __cplusplus
 }

@@ -212,6 +212,263 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
   }
 }
 
+
+// O^T-style accumulators (d in registers, row index on the lane) -> bf16 rows of `out` through a wave-private LDS slice
+template <int D>
+__device__ __forceinline__ void store_rows_from_accT(const f16v (&acc)[D / 32], float mul, char* slice, uint16_t* out,
+                                                     int64_t row_stride, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  constexpr int CPR = D / 8;
+#pragma unroll
+  for (int d = 0; d < D / 32; ++d)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ch = 4 * d + i;
+      uint2 pk;
+      pk.x = pack_bf16x2(acc[d][4 * i] * mul, acc[d][4 * i + 1] * mul);
+      pk.y = pack_bf16x2(acc[d][4 * i + 2] * mul, acc[d][4 * i + 3] * mul);
+      *reinterpret_cast<uint2*>(slice + r * (D * 2) + 16 * (ch ^ (r & (CPR - 1))) + 8 * h) = pk;
+    }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int it = 0; it < 32 * CPR / 64; ++it) {
+    const int idx = it * 64 + lane, row = idx / CPR, ch = idx % CPR;
+    const v4i val = *reinterpret_cast<const v4i*>(slice + row * (D * 2) + 16 * (ch ^ (row & (CPR - 1))));
+    *reinterpret_cast<v4i*>(out + (int64_t)row * row_stride + ch * 8) = val;
+  }
+}
+
+// dQ pass: same walk as the forward (128 query rows per workgroup, 64-key tiles).  S^T and dP^T are recomputed with the
+// query on the lane (LSE and delta are lane constants), dS^T feeds  dQ^T += K^T . dS^T  straight from the accumulators.
+// Also writes delta[b, h, q] = sum_d dO * O for the dK/dV pass.
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+                                                             const uint16_t* __restrict__ v, const uint16_t* __restrict__ o,
+                                                             const uint16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                             float* __restrict__ delta, uint16_t* __restrict__ dq, int S,
+                                                             int H, int G, int64_t q_ts, int64_t k_ts, int64_t v_ts,
+                                                             int64_t o_ts, int64_t do_ts, int64_t dq_ts, float c, float scale) {
+  constexpr int TILE = ATT_KB * D * 2;
+  constexpr int KT = D / 16, DB = D / 32;
+  __shared__ __attribute__((aligned(16))) char lds[4 * TILE];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int qb = gridDim.x - 1 - blockIdx.x, head = blockIdx.y, b = blockIdx.z, g = head / (H / G);
+  const int q_first = qb * ATT_QB + w * 32;
+  const int qrow = q_first + r;
+  const int ntiles = CAUSAL ? (qb * ATT_QB + ATT_QB) / ATT_KB : S / ATT_KB;
+  const uint16_t* kbase = k + (int64_t)b * S * k_ts + (int64_t)g * D;
+  const uint16_t* vbase = v + (int64_t)b * S * v_ts + (int64_t)g * D;
+
+  bf8 qf[KT], dof[KT];
+  float dl = 0.0f;
+  {
+    const uint16_t* qp = q + ((int64_t)b * S + qrow) * q_ts + (int64_t)head * D + 8 * h;
+    const uint16_t* dp = dout + ((int64_t)b * S + qrow) * do_ts + (int64_t)head * D + 8 * h;
+    const uint16_t* op = o + ((int64_t)b * S + qrow) * o_ts + (int64_t)head * D + 8 * h;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      qf[t] = as_bf8(*reinterpret_cast<const v4i*>(qp + 16 * t));
+      const v4i dv4 = *reinterpret_cast<const v4i*>(dp + 16 * t);
+      const v4i ov4 = *reinterpret_cast<const v4i*>(op + 16 * t);
+      dof[t] = as_bf8(dv4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32 a = (u32)dv4[j], bb = (u32)ov4[j];
+        dl += __uint_as_float(a << 16) * __uint_as_float(bb << 16) + __uint_as_float(a & 0xFFFF0000u) * __uint_as_float(bb & 0xFFFF0000u);
+      }
+    }
+  }
+  dl += __shfl_xor(dl, 32);
+  const int64_t stat = ((int64_t)b * H + head) * S + qrow;
+  if (h == 0) delta[stat] = dl;
+  const float my_lse = lse[stat];
+
+  f16v acc[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[d][i] = 0.0f;
+
+  v4i kreg[D / 32], vreg[D / 32];
+  stage_load<D>(kreg, kbase, k_ts, tid);
+  stage_load<D>(vreg, vbase, v_ts, tid);
+  stage_store<D>(kreg, lds, tid);
+  stage_store<D>(vreg, lds + 2 * TILE, tid);
+  __syncthreads();
+
+  for (int j = 0; j < ntiles; ++j) {
+    const char* kt = lds + (j & 1) * TILE;
+    const char* vt = lds + (2 + (j & 1)) * TILE;
+    const bool more = j + 1 < ntiles;
+    if (more) {
+      stage_load<D>(kreg, kbase + (int64_t)(j + 1) * ATT_KB * k_ts, k_ts, tid);
+      stage_load<D>(vreg, vbase + (int64_t)(j + 1) * ATT_KB * v_ts, v_ts, tid);
+    }
+    const int key0 = j * ATT_KB;
+    if (!CAUSAL || key0 <= q_first + 31) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        if (CAUSAL && key0 + 32 * kb > q_first + 31) continue;  // wave-uniform
+        f16v sacc, pacc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { sacc[i] = 0.0f; pacc[i] = 0.0f; }
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(kt, 32 * kb, t, lane), qf[t], sacc, 0, 0, 0);
+          pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(vt, 32 * kb, t, lane), dof[t], pacc, 0, 0, 0);
+        }
+        const bool diag = CAUSAL && key0 + 32 * kb + 31 > q_first;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[i], c, -my_lse));
+          if (diag && key0 + 32 * kb + acc_row(i, h) > qrow) p = 0.0f;
+          sacc[i] = p * (pacc[i] - dl);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const bf8 dsf = acc_frag(sacc, s);
+#pragma unroll
+          for (int d = 0; d < DB; ++d)
+            acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(kt, 32 * kb + 16 * s, 32 * d, lane), dsf, acc[d], 0, 0, 0);
+        }
+      }
+    }
+    if (more) {
+      stage_store<D>(kreg, lds + ((j + 1) & 1) * TILE, tid);
+      stage_store<D>(vreg, lds + (2 + ((j + 1) & 1)) * TILE, tid);
+    }
+    __syncthreads();
+  }
+  store_rows_from_accT<D>(acc, scale, lds + w * (32 * D * 2), dq + ((int64_t)b * S + q_first) * dq_ts + (int64_t)head * D, dq_ts, lane);
+}
+
+// dK / dV pass: one workgroup = 4 waves = 128 keys of one (batch, kv head); each wave keeps K and V rows of its 32 keys as
+// B operands (key on the lane) and dK^T, dV^T of those keys in accumulators while the workgroup sweeps the group's query
+// heads x 32-row query slices (Q and dO slices staged once for all four waves; row reads for S and dP, transposed reads
+// for the dV^T and dK^T products).
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+                                                               const uint16_t* __restrict__ v, const uint16_t* __restrict__ dout,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               uint16_t* __restrict__ dk, uint16_t* __restrict__ dv, int S, int H,
+                                                               int G, int B, int64_t q_ts, int64_t k_ts, int64_t v_ts,
+                                                               int64_t do_ts, int64_t dk_ts, int64_t dv_ts, float c, float scale) {
+  constexpr int SL = 32 * D * 2;  // bytes of one 32-row slice image
+  constexpr int KT = D / 16, DB = D / 32;
+  constexpr int BUF = 2 * SL + 256;  // Q slice, dO slice, lse[32], delta[32]
+  __shared__ __attribute__((aligned(16))) char lds[(2 * BUF > 4 * SL) ? 2 * BUF : 4 * SL];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+  // heaviest key blocks first: the key-block index is the slowest-varying part of the linear workgroup id
+  const int lin = blockIdx.x, nkb = S / 128;
+  const int kbi = CAUSAL ? lin / (G * B) : nkb - 1 - lin / (G * B);
+  const int g = (lin / B) % G, b = lin % B;
+  const int rep = H / G;
+  const int key_first = kbi * 128 + w * 32;  // first key of this wave
+  const int key = key_first + r;
+
+  bf8 kf[KT], vf[KT];
+  {
+    const uint16_t* kp = k + ((int64_t)b * S + key) * k_ts + (int64_t)g * D + 8 * h;
+    const uint16_t* vp = v + ((int64_t)b * S + key) * v_ts + (int64_t)g * D + 8 * h;
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      kf[t] = as_bf8(*reinterpret_cast<const v4i*>(kp + 16 * t));
+      vf[t] = as_bf8(*reinterpret_cast<const v4i*>(vp + 16 * t));
+    }
+  }
+  f16v dka[DB], dva[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dka[d][i] = 0.0f; dva[d][i] = 0.0f; }
+
+  const int sl0 = CAUSAL ? (kbi * 128) / 32 : 0;  // first query slice that can see this key block
+  const int nsl = S / 32 - sl0;
+  const int nsteps = rep * nsl;
+  // staging: thread -> 2 chunks of the Q slice and 2 of the dO slice; threads 0..31 lse, 32..63 delta
+  v4i qreg[2], dreg[2];
+  float sreg = 0.0f;
+  auto load_step = [&](int step) {
+    const int head = g * rep + step / nsl, q0 = (sl0 + step % nsl) * 32;
+    const uint16_t* qp = q + ((int64_t)b * S + q0) * q_ts + (int64_t)head * D;
+    const uint16_t* dp = dout + ((int64_t)b * S + q0) * do_ts + (int64_t)head * D;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int cidx = tid + 256 * i, row = cidx / (D / 8), ch = cidx % (D / 8);
+      if (D == 128 || cidx < 32 * (D / 8)) {
+        qreg[i] = *reinterpret_cast<const v4i*>(qp + (int64_t)row * q_ts + ch * 8);
+        dreg[i] = *reinterpret_cast<const v4i*>(dp + (int64_t)row * do_ts + ch * 8);
+      }
+    }
+    if (tid < 64) sreg = (tid < 32 ? lse : delta)[((int64_t)b * H + head) * S + q0 + (tid & 31)];
+  };
+  auto store_step = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int cidx = tid + 256 * i, row = cidx / (D / 8), ch = cidx % (D / 8);
+      if (D == 128 || cidx < 32 * (D / 8)) {
+        *reinterpret_cast<v4i*>(buf + tile_off<D>(row, ch)) = qreg[i];
+        *reinterpret_cast<v4i*>(buf + SL + tile_off<D>(row, ch)) = dreg[i];
+      }
+    }
+    if (tid < 64) reinterpret_cast<float*>(buf + 2 * SL)[tid] = sreg;
+  };
+  load_step(0);
+  store_step(lds);
+  __syncthreads();
+
+  for (int step = 0; step < nsteps; ++step) {
+    const char* buf = lds + (step & 1) * BUF;
+    const bool more = step + 1 < nsteps;
+    if (more) load_step(step + 1);
+    const int q0 = (sl0 + step % nsl) * 32;
+    if (!CAUSAL || q0 + 31 >= key_first) {  // wave-uniform: slices entirely before this wave's keys see none of them
+      const char* qt = buf;
+      const char* dt = buf + SL;
+      const float* st = reinterpret_cast<const float*>(buf + 2 * SL);
+      f16v sacc, pacc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { sacc[i] = 0.0f; pacc[i] = 0.0f; }
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(qt, 0, t, lane), kf[t], sacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(dt, 0, t, lane), vf[t], pacc, 0, 0, 0);
+      }
+      const bool diag = CAUSAL && q0 < key_first + 31;
+      f16v dsacc;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const v4f ls = *reinterpret_cast<const v4f*>(st + 8 * a + 4 * h);
+        const v4f dl = *reinterpret_cast<const v4f*>(st + 32 + 8 * a + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * a + e;
+          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[i], c, -ls[e]));
+          if (diag && key > q0 + acc_row(i, h)) p = 0.0f;
+          sacc[i] = p;
+          dsacc[i] = p * (pacc[i] - dl[e]);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf8 pf = acc_frag(sacc, s), dsf = acc_frag(dsacc, s);
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+          dva[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(dt, 16 * s, 32 * d, lane), pf, dva[d], 0, 0, 0);
+          dka[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(qt, 16 * s, 32 * d, lane), dsf, dka[d], 0, 0, 0);
+        }
+      }
+    }
+    if (more) store_step(lds + ((step + 1) & 1) * BUF);
+    __syncthreads();
+  }
+  char* slice = lds + w * SL;
+  store_rows_from_accT<D>(dka, scale, slice, dk + ((int64_t)b * S + key_first) * dk_ts + (int64_t)g * D, dk_ts, lane);
+  __builtin_amdgcn_wave_barrier();
+  store_rows_from_accT<D>(dva, 1.0f, slice, dv + ((int64_t)b * S + key_first) * dv_ts + (int64_t)g * D, dv_ts, lane);
+}
+
 }  // namespace mi
 
 extern "C" int mi_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int S, int H, int G,
@@ -233,5 +490,37 @@ extern "C" int mi_attn_fwd(const void* q, const void* k, const void* v, void* o,
     hipLaunchKernelGGL((mi::attn_fwd_kernel<128, false>), grid, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,
                        (const uint16_t*)v, (uint16_t*)o, lse, S, H, G, q_ts, k_ts, v_ts, o_ts, c);
   MI_CHECK_LAUNCH("mi_attn_fwd launch");
+  return MI_OK;
+}
+
+extern "C" int mi_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                           float* delta, void* dq, void* dk, void* dv, int B, int S, int H, int G, int D, int64_t q_ts,
+                           int64_t k_ts, int64_t v_ts, int64_t o_ts, int64_t do_ts, int64_t dq_ts, int64_t dk_ts,
+                           int64_t dv_ts, float scale, int causal, void* stream) {
+  MI_CHECK_ARG(q && k && v && o && dout && lse && delta && dq && dk && dv, "mi_attn_bwd: null pointer");
+  MI_CHECK_ARG(B >= 1 && H >= 1 && G >= 1 && H % G == 0, "mi_attn_bwd: bad B/H/G (%d, %d, %d)", B, H, G);
+  MI_CHECK_ARG(D == 128, "mi_attn_bwd: head_dim %d not supported (128)", D);
+  MI_CHECK_ARG(S >= 128 && S % 128 == 0, "mi_attn_bwd: seq %d must be a multiple of 128", S);
+  MI_CHECK_ARG((q_ts | k_ts | v_ts | o_ts | do_ts | dq_ts | dk_ts | dv_ts) % 8 == 0, "mi_attn_bwd: token strides must be multiples of 8");
+  MI_CHECK_ARG(H <= 65535 && B <= 65535, "mi_attn_bwd: grid too large");
+  const float c = scale * 1.4426950408889634f;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid_q(S / mi::ATT_QB, H, B), grid_kv((unsigned)((int64_t)(S / 128) * G * B)), block(256);
+  if (causal) {
+    hipLaunchKernelGGL((mi::attn_bwd_dq_kernel<128, true>), grid_q, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,
+                       (const uint16_t*)v, (const uint16_t*)o, (const uint16_t*)dout, lse, delta, (uint16_t*)dq, S, H, G, q_ts,
+                       k_ts, v_ts, o_ts, do_ts, dq_ts, c, scale);
+    hipLaunchKernelGGL((mi::attn_bwd_dkdv_kernel<128, true>), grid_kv, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,
+                       (const uint16_t*)v, (const uint16_t*)dout, lse, delta, (uint16_t*)dk, (uint16_t*)dv, S, H, G, B, q_ts,
+                       k_ts, v_ts, do_ts, dk_ts, dv_ts, c, scale);
+  } else {
+    hipLaunchKernelGGL((mi::attn_bwd_dq_kernel<128, false>), grid_q, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,
+                       (const uint16_t*)v, (const uint16_t*)o, (const uint16_t*)dout, lse, delta, (uint16_t*)dq, S, H, G, q_ts,
+                       k_ts, v_ts, o_ts, do_ts, dq_ts, c, scale);
+    hipLaunchKernelGGL((mi::attn_bwd_dkdv_kernel<128, false>), grid_kv, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,
+                       (const uint16_t*)v, (const uint16_t*)dout, lse, delta, (uint16_t*)dk, (uint16_t*)dv, S, H, G, B, q_ts,
+                       k_ts, v_ts, do_ts, dk_ts, dv_ts, c, scale);
+  }
+  MI_CHECK_LAUNCH("mi_attn_bwd launch");
   return MI_OK;
 }

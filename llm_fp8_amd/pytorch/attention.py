@@ -2,9 +2,10 @@
 `MultiheadAttention(...)`(hidden_states, attention_mask=, rotary_pos_emb=) and
 `attention.RotaryPositionEmbedding(dim)(max_seq_len)`.
 
-Only the two projections (`layernorm_qkv`, `proj`) are on the FP8 hot path; the attention core is
-bf16 `scaled_dot_product_attention` on ROCm (the reference's core is bf16 flash-attn, out of scope:
-SURVEY.md 2.3 K11)."""
+The two projections (`layernorm_qkv`, `proj`) are on the FP8 hot path; the attention core is bf16 (the
+reference's core is bf16 flash-attn through TE, README.md:27-28): the hand-written flash-style HIP kernels of
+csrc/mi_attn.hip for the shapes of the reference's configs (causal, head_dim 128, seq % 128 == 0, no dropout),
+torch `scaled_dot_product_attention` otherwise."""
 from __future__ import annotations
 
 from typing import Optional
@@ -99,6 +100,33 @@ class _RoPESplitFn(torch.autograd.Function):
         return g.view(B, S, -1), None, None, None, None, None
 
 
+class _FlashAttnFn(torch.autograd.Function):
+    """bshd attention core on mi_attn_fwd / mi_attn_bwd; saves q, k, v, o and the log-sum-exp, never the scores."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale, causal):
+        o, lse = ops.attn_fwd(q, k, v, scale, causal)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.scale, ctx.causal = scale, causal
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        do = do if (do.stride(3) == 1 and do.stride(2) == do.shape[3] and do.stride(0) == do.shape[1] * do.stride(1)) else do.contiguous()
+        dq, dk, dv = ops.attn_bwd(do, q, k, v, o, lse, ctx.scale, ctx.causal)
+        return dq, dk, dv, None, None
+
+
+def _flash_ok(q, k, v, causal: bool, dropout: float) -> bool:
+    if not (q.is_cuda and q.dtype == k.dtype == v.dtype == torch.bfloat16 and dropout == 0.0 and causal):
+        return False
+    B, S, H, D = q.shape
+    if D != 128 or S % 128 or S < 128 or H % k.shape[2]:
+        return False
+    return all(t.stride(3) == 1 and t.stride(2) == D and t.stride(0) == S * t.stride(1) and t.stride(1) % 8 == 0 for t in (q, k, v))
+
+
 class DotProductAttention(torch.nn.Module):
     """bf16 attention core.  q [b,s,h,d], k/v [b,s,g,d] (bshd) -> [b,s,h*d]."""
 
@@ -112,8 +140,13 @@ class DotProductAttention(torch.nn.Module):
     def forward(self, q, k, v, attention_mask=None):
         if self.qkv_format == "sbhd":
             q, k, v = (t.transpose(0, 1) for t in (q, k, v))
-        q, k, v = (t.transpose(1, 2) for t in (q, k, v))  # [b, h, s, d]
         causal = self.attn_mask_type in ("causal", "padding_causal")
+        if _flash_ok(q, k, v, causal, self.p if self.training else 0.0):
+            o = _FlashAttnFn.apply(q, k, v, self.d ** -0.5, True)
+            if self.qkv_format == "sbhd":
+                o = o.transpose(0, 1)
+            return o.reshape(*o.shape[:2], self.h * self.d)
+        q, k, v = (t.transpose(1, 2) for t in (q, k, v))  # [b, h, s, d]
         mask = None
         if not causal and attention_mask is not None:
             mask = ~attention_mask if attention_mask.dtype == torch.bool else attention_mask  # TE: True = masked out

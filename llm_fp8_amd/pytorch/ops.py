@@ -368,3 +368,34 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, ca
             rc = _lib.load().mi_attn_fwd(*args)
     _lib.check(rc, "mi_attn_fwd")
     return o, lse
+
+
+def attn_bwd(do: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, lse: torch.Tensor,
+             scale: float, causal: bool = True, out=None):
+    """Backward of attn_fwd -> (dq [B,S,H,D], dk, dv [B,S,G,D]).  `out` = optional preallocated (dq, dk, dv) views."""
+    _dev(do, q, k, v, o, lse)
+    B, S, H, D = q.shape
+    G = k.shape[2]
+    for t in (q, k, v, o, do):
+        _bshd_ok(t, D)
+    if out is None:
+        dq = torch.empty((B, S, H, D), dtype=torch.bfloat16, device=q.device)
+        dk = torch.empty((B, S, G, D), dtype=torch.bfloat16, device=q.device)
+        dv = torch.empty((B, S, G, D), dtype=torch.bfloat16, device=q.device)
+    else:
+        dq, dk, dv = out
+        for t in out:
+            _bshd_ok(t, D)
+    delta = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
+    args = (q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, S, H, G, D, q.stride(1), k.stride(1), v.stride(1), o.stride(1),
+            do.stride(1), dq.stride(1), dk.stride(1), dv.stride(1), float(scale), int(causal), _stream())
+    t = KernelTimer.active
+    flops = 14.0 * B * H * S * S * D * (0.5 if causal else 1.0)  # 7 products: S, dP, dQ | S, dP, dV, dK
+    if t is None:
+        rc = _lib.load().mi_attn_bwd(*args)
+    else:
+        with t.span("attn_bwd", f"{B}x{S}x{H}x{D}", flops, 2.0 * (3 * q.numel() + 4 * k.numel())):
+            rc = _lib.load().mi_attn_bwd(*args)
+    _lib.check(rc, "mi_attn_bwd")
+    return dq, dk, dv

@@ -488,3 +488,43 @@ def test_attn_fwd_strided_views_and_full_size(ops, dev):
     err = (o.float() - o_ref).abs().max().item()
     assert err < 2 ** -6 * float(v.abs().max()), err
     assert (lse - lse_ref).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("B,S,H,G", [(1, 128, 2, 1), (2, 256, 6, 2), (1, 512, 3, 3)])
+@pytest.mark.parametrize("causal", [True, False])
+def test_attn_bwd_vs_oracle(ops, dev, B, S, H, G, causal):
+    D = 128
+    g = torch.Generator().manual_seed(S + H + 1)
+    q, k, v = (torch.randn(B, S, n, D, generator=g).to(torch.bfloat16) for n in (H, G, G))
+    do = (torch.randn(B, S, H, D, generator=g) / 4).to(torch.bfloat16)
+    scale = D ** -0.5
+    dq_r, dk_r, dv_r = O.attention_bwd_f64(bf16_bits(q), bf16_bits(k), bf16_bits(v), bf16_bits(do), scale, causal)
+    qd, kd, vd, dod = (t.to(dev) for t in (q, k, v, do))
+    o, lse = ops.attn_fwd(qd, kd, vd, scale, causal)
+    dq, dk, dv = ops.attn_bwd(dod, qd, kd, vd, o, lse, scale, causal)
+    for got, ref, name in ((dq, dq_r, "dq"), (dk, dk_r, "dk"), (dv, dv_r, "dv")):
+        got = got.float().cpu().numpy()
+        # P, dS and the outputs are rounded to bf16 (2^-8 each); errors add over the contraction like a random walk
+        tol = 2 ** -6 * np.abs(ref) + 2 ** -7 * np.sqrt(np.mean(ref.astype(np.float64) ** 2))
+        bad = np.abs(got - ref) > tol
+        assert bad.mean() < 1e-3, f"{name}: {bad.sum()} / {bad.size} outside tolerance, max diff {np.abs(got - ref).max():.4g}"
+        rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        assert rel < 6e-3, f"{name}: relative Frobenius error {rel:.4g}"
+
+
+def test_attn_bwd_full_size_vs_torch_autograd_and_reproducible(ops, dev):
+    B, S, H, G, D = 4, 512, 24, 8, 128
+    g = torch.Generator(device=dev).manual_seed(2)
+    q, k, v = (torch.randn(B, S, n, D, device=dev, dtype=torch.bfloat16, generator=g) for n in (H, G, G))
+    do = torch.randn(B, S, H, D, device=dev, dtype=torch.bfloat16, generator=g) / 4
+    scale = D ** -0.5
+    o, lse = ops.attn_fwd(q, k, v, scale, True)
+    dq, dk, dv = ops.attn_bwd(do, q, k, v, o, lse, scale, True)
+    dq2, dk2, dv2 = ops.attn_bwd(do, q, k, v, o, lse, scale, True)
+    assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)  # no atomics: bitwise reproducible
+    qr, kr, vr = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    o_ref, _ = _torch_attn_ref(qr, kr, vr, scale, True)
+    o_ref.backward(do.float())
+    for got, ref, name in ((dq, qr.grad, "dq"), (dk, kr.grad, "dk"), (dv, vr.grad, "dv")):
+        rel = ((got.float() - ref).norm() / ref.norm()).item()
+        assert rel < 6e-3, f"{name}: {rel:.4g}"

@@ -461,3 +461,28 @@ def test_is_first_microbatch_reuses_fp8_weights(te, dev, kind):
     rel = (y_reuse.float() - y_recast.float()).norm() / y_recast.float().norm()
     assert rel < 0.02  # weights unchanged: only the (delayed) scale the weights were quantised with differs
     assert torch.isfinite(mod.fc1_weight.grad if kind == "mlp" else mod.weight.grad).all()
+
+
+def test_dot_product_attention_flash_path_matches_sdpa(te, dev):
+    """DotProductAttention on the hand-written kernels vs the torch SDPA route (same module, flash path disabled)."""
+    from llm_fp8_amd.pytorch import attention as A
+    B, S, H, G, D = 2, 256, 6, 2, 128
+    core = A.DotProductAttention(H, D, G, attention_dropout=0.0, attn_mask_type="causal", qkv_format="bshd")
+    torch.manual_seed(3)
+    q, k, v = (torch.randn(B, S, n, D, device=dev, dtype=torch.bfloat16, requires_grad=True) for n in (H, G, G))
+    assert A._flash_ok(q, k, v, True, 0.0)
+    o = core(q, k, v)
+    go = torch.randn_like(o) / 4
+    o.backward(go)
+    got = (o.detach(), q.grad.clone(), k.grad.clone(), v.grad.clone())
+    q.grad = k.grad = v.grad = None
+    saved = A._flash_ok
+    A._flash_ok = lambda *a, **kw: False
+    try:
+        o2 = core(q, k, v)
+        o2.backward(go)
+    finally:
+        A._flash_ok = saved
+    for a, b, name in zip(got, (o2.detach(), q.grad, k.grad, v.grad), ("o", "dq", "dk", "dv")):
+        rel = ((a.float() - b.float()).norm() / b.float().norm()).item()
+        assert rel < 1e-2, f"{name}: {rel:.4g}"
