@@ -199,7 +199,7 @@ int mi_adamw_bf16(void* p_bf16, const void* g_bf16, void* exp_avg_bf16, void* ex
  * num_gqa_groups, qkv_format="bshd", attention_dropout 0; TE dispatches to flash-attn, README.md:27-28).  bf16 in/out,
  * fp32 softmax statistics, scores never written to memory.
  *   q, o [B, S, H, D]; k, v [B, S, G, D] (H % G == 0), D contiguous, `*_ts` = token stride in elements (multiple of 8), so
- *   the operands may be column slices of one fused [tokens, (H + 2G) * D] buffer.  D = 128, S % 128 == 0.
+ *   the operands may be column slices of one fused [tokens, (H + 2G) * D] buffer.  D in {64, 128}, S % 128 == 0.
  *   lse [B, H, S] fp32 = log2-domain log-sum-exp (max * c + log2(sum), c = scale * log2(e)); kept for the backward.
  */
 int mi_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int S, int H, int G, int D,

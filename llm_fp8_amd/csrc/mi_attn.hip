@@ -476,19 +476,22 @@ extern "C" int mi_attn_fwd(const void* q, const void* k, const void* v, void* o,
                            void* stream) {
   MI_CHECK_ARG(q && k && v && o && lse, "mi_attn_fwd: null pointer");
   MI_CHECK_ARG(B >= 1 && H >= 1 && G >= 1 && H % G == 0, "mi_attn_fwd: bad B/H/G (%d, %d, %d)", B, H, G);
-  MI_CHECK_ARG(D == 128, "mi_attn_fwd: head_dim %d not supported (128)", D);
+  MI_CHECK_ARG(D == 128 || D == 64, "mi_attn_fwd: head_dim %d not supported (64, 128)", D);
   MI_CHECK_ARG(S >= 128 && S % 128 == 0, "mi_attn_fwd: seq %d must be a multiple of 128", S);
   MI_CHECK_ARG(q_ts % 8 == 0 && k_ts % 8 == 0 && v_ts % 8 == 0 && o_ts % 8 == 0, "mi_attn_fwd: token strides must be multiples of 8");
   MI_CHECK_ARG(H <= 65535 && B <= 65535, "mi_attn_fwd: grid too large");
   const float c = scale * 1.4426950408889634f;
   dim3 grid(S / mi::ATT_QB, H, B), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (causal)
-    hipLaunchKernelGGL((mi::attn_fwd_kernel<128, true>), grid, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,
-                       (const uint16_t*)v, (uint16_t*)o, lse, S, H, G, q_ts, k_ts, v_ts, o_ts, c);
-  else
-    hipLaunchKernelGGL((mi::attn_fwd_kernel<128, false>), grid, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,
-                       (const uint16_t*)v, (uint16_t*)o, lse, S, H, G, q_ts, k_ts, v_ts, o_ts, c);
+#define MI_ATTN_FWD(DD, CC)                                                                                            \
+  hipLaunchKernelGGL((mi::attn_fwd_kernel<DD, CC>), grid, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,          \
+                     (const uint16_t*)v, (uint16_t*)o, lse, S, H, G, q_ts, k_ts, v_ts, o_ts, c)
+  if (D == 128) {
+    if (causal) MI_ATTN_FWD(128, true); else MI_ATTN_FWD(128, false);
+  } else {
+    if (causal) MI_ATTN_FWD(64, true); else MI_ATTN_FWD(64, false);
+  }
+#undef MI_ATTN_FWD
   MI_CHECK_LAUNCH("mi_attn_fwd launch");
   return MI_OK;
 }
@@ -499,28 +502,28 @@ extern "C" int mi_attn_bwd(const void* q, const void* k, const void* v, const vo
                            int64_t dv_ts, float scale, int causal, void* stream) {
   MI_CHECK_ARG(q && k && v && o && dout && lse && delta && dq && dk && dv, "mi_attn_bwd: null pointer");
   MI_CHECK_ARG(B >= 1 && H >= 1 && G >= 1 && H % G == 0, "mi_attn_bwd: bad B/H/G (%d, %d, %d)", B, H, G);
-  MI_CHECK_ARG(D == 128, "mi_attn_bwd: head_dim %d not supported (128)", D);
+  MI_CHECK_ARG(D == 128 || D == 64, "mi_attn_bwd: head_dim %d not supported (64, 128)", D);
   MI_CHECK_ARG(S >= 128 && S % 128 == 0, "mi_attn_bwd: seq %d must be a multiple of 128", S);
   MI_CHECK_ARG((q_ts | k_ts | v_ts | o_ts | do_ts | dq_ts | dk_ts | dv_ts) % 8 == 0, "mi_attn_bwd: token strides must be multiples of 8");
   MI_CHECK_ARG(H <= 65535 && B <= 65535, "mi_attn_bwd: grid too large");
   const float c = scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid_q(S / mi::ATT_QB, H, B), grid_kv((unsigned)((int64_t)(S / 128) * G * B)), block(256);
-  if (causal) {
-    hipLaunchKernelGGL((mi::attn_bwd_dq_kernel<128, true>), grid_q, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,
-                       (const uint16_t*)v, (const uint16_t*)o, (const uint16_t*)dout, lse, delta, (uint16_t*)dq, S, H, G, q_ts,
-                       k_ts, v_ts, o_ts, do_ts, dq_ts, c, scale);
-    hipLaunchKernelGGL((mi::attn_bwd_dkdv_kernel<128, true>), grid_kv, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,
-                       (const uint16_t*)v, (const uint16_t*)dout, lse, delta, (uint16_t*)dk, (uint16_t*)dv, S, H, G, B, q_ts,
-                       k_ts, v_ts, do_ts, dk_ts, dv_ts, c, scale);
+#define MI_ATTN_BWD(DD, CC)                                                                                            \
+  do {                                                                                                                 \
+    hipLaunchKernelGGL((mi::attn_bwd_dq_kernel<DD, CC>), grid_q, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,   \
+                       (const uint16_t*)v, (const uint16_t*)o, (const uint16_t*)dout, lse, delta, (uint16_t*)dq, S, H,  \
+                       G, q_ts, k_ts, v_ts, o_ts, do_ts, dq_ts, c, scale);                                               \
+    hipLaunchKernelGGL((mi::attn_bwd_dkdv_kernel<DD, CC>), grid_kv, block, 0, st, (const uint16_t*)q,                    \
+                       (const uint16_t*)k, (const uint16_t*)v, (const uint16_t*)dout, lse, delta, (uint16_t*)dk,        \
+                       (uint16_t*)dv, S, H, G, B, q_ts, k_ts, v_ts, do_ts, dk_ts, dv_ts, c, scale);                      \
+  } while (0)
+  if (D == 128) {
+    if (causal) MI_ATTN_BWD(128, true); else MI_ATTN_BWD(128, false);
   } else {
-    hipLaunchKernelGGL((mi::attn_bwd_dq_kernel<128, false>), grid_q, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,
-                       (const uint16_t*)v, (const uint16_t*)o, (const uint16_t*)dout, lse, delta, (uint16_t*)dq, S, H, G, q_ts,
-                       k_ts, v_ts, o_ts, do_ts, dq_ts, c, scale);
-    hipLaunchKernelGGL((mi::attn_bwd_dkdv_kernel<128, false>), grid_kv, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,
-                       (const uint16_t*)v, (const uint16_t*)dout, lse, delta, (uint16_t*)dk, (uint16_t*)dv, S, H, G, B, q_ts,
-                       k_ts, v_ts, do_ts, dk_ts, dv_ts, c, scale);
+    if (causal) MI_ATTN_BWD(64, true); else MI_ATTN_BWD(64, false);
   }
+#undef MI_ATTN_BWD
   MI_CHECK_LAUNCH("mi_attn_bwd launch");
   return MI_OK;
 }

@@ -4,7 +4,7 @@
 
 The two projections (`layernorm_qkv`, `proj`) are on the FP8 hot path; the attention core is bf16 (the
 reference's core is bf16 flash-attn through TE, README.md:27-28): the hand-written flash-style HIP kernels of
-csrc/mi_attn.hip for the shapes of the reference's configs (causal, head_dim 128, seq % 128 == 0, no dropout),
+csrc/mi_attn.hip for the shapes of the reference's configs (causal, head_dim 64 / 128, seq % 128 == 0, no dropout),
 torch `scaled_dot_product_attention` otherwise."""
 from __future__ import annotations
 
@@ -122,7 +122,7 @@ def _flash_ok(q, k, v, causal: bool, dropout: float) -> bool:
     if not (q.is_cuda and q.dtype == k.dtype == v.dtype == torch.bfloat16 and dropout == 0.0 and causal):
         return False
     B, S, H, D = q.shape
-    if D != 128 or S % 128 or S < 128 or H % k.shape[2]:
+    if D not in (64, 128) or S % 128 or S < 128 or H % k.shape[2]:
         return False
     return all(t.stride(3) == 1 and t.stride(2) == D and t.stride(0) == S * t.stride(1) and t.stride(1) % 8 == 0 for t in (q, k, v))
 

@@ -460,8 +460,8 @@ def _torch_attn_ref(q, k, v, scale, causal=True):
 
 @pytest.mark.parametrize("B,S,H,G", [(1, 128, 2, 1), (2, 256, 6, 2), (1, 512, 3, 3)])
 @pytest.mark.parametrize("causal", [True, False])
-def test_attn_fwd_vs_oracle(ops, dev, B, S, H, G, causal):
-    D = 128
+@pytest.mark.parametrize("D", [128, 64])
+def test_attn_fwd_vs_oracle(ops, dev, B, S, H, G, causal, D):
     g = torch.Generator().manual_seed(S + H)
     q, k, v = (torch.randn(B, S, n, D, generator=g).to(torch.bfloat16) for n in (H, G, G))
     q = q * 2.0  # sharper softmax
@@ -492,8 +492,8 @@ def test_attn_fwd_strided_views_and_full_size(ops, dev):
 
 @pytest.mark.parametrize("B,S,H,G", [(1, 128, 2, 1), (2, 256, 6, 2), (1, 512, 3, 3)])
 @pytest.mark.parametrize("causal", [True, False])
-def test_attn_bwd_vs_oracle(ops, dev, B, S, H, G, causal):
-    D = 128
+@pytest.mark.parametrize("D", [128, 64])
+def test_attn_bwd_vs_oracle(ops, dev, B, S, H, G, causal, D):
     g = torch.Generator().manual_seed(S + H + 1)
     q, k, v = (torch.randn(B, S, n, D, generator=g).to(torch.bfloat16) for n in (H, G, G))
     do = (torch.randn(B, S, H, D, generator=g) / 4).to(torch.bfloat16)

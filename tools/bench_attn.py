@@ -21,7 +21,7 @@ def timeit(fn, n=30, warm=5):
     return a.elapsed_time(b) / n * 1e3
 
 
-for (B, S, H, G, D) in [(16, 512, 24, 8, 128), (12, 512, 32, 8, 128), (4, 2048, 24, 8, 128)]:
+for (B, S, H, G, D) in [(16, 512, 24, 8, 128), (12, 512, 32, 8, 128), (4, 2048, 24, 8, 128), (16, 512, 32, 8, 64)]:
     q, k, v = (torch.randn(B, S, n, D, device=dev, dtype=torch.bfloat16) for n in (H, G, G))
     scale = D ** -0.5
     fl = 4.0 * B * H * S * S * D * 0.5
