@@ -83,11 +83,23 @@ int mi_scale_update(float* amax_history, float* scale, float* scale_inv, const f
  * algo: 0 = auto, 1 = generic 64x64 tile, 2 = 256x256 two-phase, 3 = 256x256 eight-phase ping-pong,
  *       4 = persistent eight-phase (one workgroup per CU, epilogue overlapped with the next tile).
  * 2/3 need M,N % 256 == 0 and K % 128 == 0; 4 additionally K % 256 == 0, bf16 output and operands
- * below 2 GiB.  auto picks 4, else 3, else 1.  (13-15 are timing-only diagnostic builds.)
+ * below 2 GiB (M, N may also be multiples of 192: workgroup tiles of 256/192 rows x 256/192 columns are picked per shape).
+ * auto picks 4, else 3, else 1.  40-43 force one tile shape of 4, 44 = stream-K form of 4 (see mi_gemm_set_workspace),
+ * 45 = 4; 13-17 are timing-only diagnostic builds.
  */
 int mi_gemm_fp8(const void* A, const void* B, void* D, const float* sa_inv, const float* sb_inv,
                 const void* bias_bf16, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                 int64_t ldd, int fmt_a, int fmt_b, int out_dtype, int algo, void* stream);
+
+/*
+ * Stream-K workspace for the persistent GEMM, used only by the explicit algo 44: when the 256x256 tile count is not a
+ * multiple of the CU count, the (tile, K-tile) steps are cut into equal ranges and a tile split between two workgroups is
+ * summed through this buffer (fp32 partial accumulators + one flag per workgroup).  The caller owns the memory: at least
+ * mi_gemm_workspace_bytes(), 256-byte aligned, its first 4 KiB zeroed once; it is bound to the CURRENT device until replaced
+ * (NULL unregisters) and must only be used by GEMMs of one stream at a time.
+ */
+int64_t mi_gemm_workspace_bytes(void);
+int mi_gemm_set_workspace(void* workspace, int64_t bytes);
 
 /*
  * K7  MXFP8 block quantise  [replaces TE's MXFP8 quantize, row-wise and column-wise].

@@ -37,6 +37,8 @@ SIGNATURES = {
     "mi_sumsq_bf16": [_p, _c_i64, _p, _c_int, _p],
     "mi_adamw_bf16": [_p, _p, _p, _p, _c_i64, _p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                       ctypes.c_float, _c_i64, _p],
+    "mi_gemm_workspace_bytes": [],
+    "mi_gemm_set_workspace": [_p, _c_i64],
     "mi_attn_fwd": [_p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_i64, ctypes.c_float,
                     _c_int, _p],
     "mi_attn_bwd": [_p] * 10 + [_c_int] * 5 + [_c_i64] * 8 + [ctypes.c_float, _c_int, _p],
@@ -63,7 +65,7 @@ def load() -> ctypes.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_char_p if name == "mi_last_error" else _c_int
+        fn.restype = ctypes.c_char_p if name == "mi_last_error" else (_c_i64 if name == "mi_gemm_workspace_bytes" else _c_int)
     v = lib.mi_abi_version()
     if v != ABI_VERSION:
         raise ImportError(f"libmi_fp8.so ABI version {v} != expected {ABI_VERSION}; rebuild it")

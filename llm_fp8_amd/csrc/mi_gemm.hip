@@ -30,6 +30,7 @@
 // Replaces the cuBLASLt FP8 GEMMs behind te.Linear / LayerNormLinear / LayerNormMLP on the
 // reference path (te_llama.py:45-63,76-80; Appendix B shapes).
 #include "mi_common.h"
+#include <atomic>
 #include <type_traits>
 
 namespace mi {
@@ -152,6 +153,17 @@ __device__ __forceinline__ void tile_of_block(int bid, int nwg, int tiles_m, int
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   constexpr int GM = 4;  // super-rows of 4 tile-rows, column-major inside
+  int group = id / (GM * tiles_n);
+  int first_m = group * GM;
+  int gsz = min(tiles_m - first_m, GM);
+  int in_g = id - group * GM * tiles_n;
+  tm = first_m + in_g % gsz;
+  tn = in_g / gsz;
+}
+
+// grouped order only (stream-K: consecutive flat ids belong to consecutive workgroups of one XCD)
+__device__ __forceinline__ void tile_of_flat(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
+  constexpr int GM = 4;
   int group = id / (GM * tiles_n);
   int first_m = group * GM;
   int gsz = min(tiles_m - first_m, GM);
@@ -468,14 +480,22 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // Requires K % 256 == 0 (an even number of K-tiles, so every tile starts on LDS buffer 0) and
 // operand / output footprints < 2^31 bytes (32-bit buffer offsets); the host dispatcher checks both.
-template <int FA, int FB, int ABL = 0, bool MX = false, bool BIAS = false, int MA1 = 4, int NB1 = 2>
+//
+// SK (stream-K): when the tile count is not a multiple of the CU count, the flattened (tile, K-tile) steps are cut into
+// equal contiguous ranges, one per workgroup (range length U >= K-tiles per tile, even).  A range may START inside a tile:
+// that tail part is computed FIRST, its fp32 accumulators go to workspace slot v (write-through stores, vmcnt(0), barrier,
+// then one lane publishes flags[v] = epoch).  A range may END inside a tile: that head part is computed LAST; the
+// workgroup then waits for flags[v + 1] == epoch (set long before, the neighbour produced it first thing), adds the
+// neighbour's partial accumulators and runs the normal epilogue.  Producers never wait, so there is no cycle.
+template <int FA, int FB, int ABL = 0, bool MX = false, bool BIAS = false, int MA1 = 4, int NB1 = 2, bool SK = false>
 __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
                                                       uint16_t* __restrict__ D, const float* __restrict__ sa_inv,
                                                       const float* __restrict__ sb_inv, int K, int lda, int ldb,
                                                       int ldd, int tiles_m, int tiles_n, int a_bytes, int b_bytes,
                                                       int d_bytes, const uint8_t* __restrict__ SA,
                                                       const uint8_t* __restrict__ SB, int M, int N,
-                                                      const uint16_t* __restrict__ bias) {
+                                                      const uint16_t* __restrict__ bias, float* __restrict__ sk_ws,
+                                                      unsigned int* __restrict__ sk_flags, unsigned int sk_epoch, int sk_U) {
   constexpr int RA0 = 64, RA1 = 16 * MA1, RB0 = 32, RB1 = 16 * NB1;  // rows of A / B per wave in half 0 / 1
   constexpr int TBM = 2 * (RA0 + RA1), TBN = 4 * (RB0 + RB1);        // workgroup tile
   constexpr int nA1 = MA1 / 2, nB1 = NB1;                            // LDS-DMA pieces per wave of the second halves
@@ -491,8 +511,18 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   const int ntiles = tiles_m * tiles_n;
   const int G = gridDim.x;
   const int bid = blockIdx.x;
-  const int my_tiles = (ntiles - bid + G - 1) / G;  // tiles bid, bid + G, ...
   const int nk = K / BK;
+  // SK: virtual index v = XCD-major order of the workgroups (neighbours in v share an L2), range [v U, (v + 1) U)
+  int sk_v = 0, sk_t0 = 0, sk_k0 = 0, sk_total = 0;
+  if (SK) {
+    const int q8 = G >> 3, r8 = G & 7, xcd = bid & 7;
+    sk_v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int u0 = sk_v * sk_U, u1 = min(u0 + sk_U, ntiles * nk);
+    sk_t0 = u0 / nk;
+    sk_k0 = u0 - sk_t0 * nk;
+    sk_total = u1 - u0;
+  }
+  const int my_tiles = SK ? 0 : (ntiles - bid + G - 1) / G;  // tiles bid, bid + G, ...
   const float alpha = MX ? 1.0f : (*sa_inv) * (*sb_inv);
   const rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
   const rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
@@ -553,17 +583,21 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   }
 
   // pipeline cursors (wave-uniform byte offsets of the (tile, K-tile) of step s+1 / s+2, clamped to the last step)
-  const int total = my_tiles * nk;
+  const int total = SK ? sk_total : my_tiles * nk;
+  auto tile_mn = [&](int ti, int& tm, int& tn) {
+    if (SK) tile_of_flat(sk_t0 + ti, tiles_m, tiles_n, tm, tn);
+    else tile_of_block(bid + ti * G, ntiles, tiles_m, tiles_n, tm, tn);
+  };
   auto tile_origin = [&](int ti, int& oa, int& ob, int& ra, int& rb) {
     int tm, tn;
-    tile_of_block(bid + ti * G, ntiles, tiles_m, tiles_n, tm, tn);
+    tile_mn(ti, tm, tn);
     ra = tm * TBM;
     rb = tn * TBN;
     oa = ra * lda;
     ob = rb * ldb;
   };
   int ra_1 = 0, rb_1 = 0;
-  int oa_1, ob_1, oa_2, ob_2, ti_1 = 0, kt_1 = 0, ti_2 = 0, kt_2 = 0;
+  int oa_1, ob_1, oa_2, ob_2, ti_1 = 0, kt_1 = SK ? sk_k0 : 0, ti_2 = 0, kt_2 = 0;
   int oa_0, ob_0, ra_0, rb_0, ra_2, rb_2;
   tile_origin(0, oa_0, ob_0, ra_0, rb_0);
   oa_1 = oa_2 = oa_0;
@@ -586,12 +620,13 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   uint8_t* const buf0 = lds;
   uint8_t* const buf1 = lds + kBufBytes;
   // prologue: step 0 complete, (step 1: A0, B0) in flight
-  stage_scales(0, 0, ra_0, rb_0);
+  const int kb0 = SK ? sk_k0 * BK : 0;  // first step's K offset (bytes)
+  stage_scales(0, SK ? sk_k0 : 0, ra_0, rb_0);
   stage_bias(0, rb_0);
-  stage_n<2>(rsA, a0_voff, oa_0, buf0 + kOffA0, wave);
-  stage_n<2>(rsB, b0_voff, ob_0, buf0 + kOffB0, wave);
-  stage_n<nB1>(rsB, b1_voff, ob_0, buf0 + kOffB1, wave);
-  stage_n<nA1>(rsA, a1_voff, oa_0, buf0 + kOffA1, wave);
+  stage_n<2>(rsA, a0_voff, oa_0 + kb0, buf0 + kOffA0, wave);
+  stage_n<2>(rsB, b0_voff, ob_0 + kb0, buf0 + kOffB0, wave);
+  stage_n<nB1>(rsB, b1_voff, ob_0 + kb0, buf0 + kOffB1, wave);
+  stage_n<nA1>(rsA, a1_voff, oa_0 + kb0, buf0 + kOffA1, wave);
   stage_n<2>(rsA, a0_voff, oa_1 + kt_1 * BK, buf1 + kOffA0, wave);
   stage_n<2>(rsB, b0_voff, ob_1 + kt_1 * BK, buf1 + kOffB0, wave);
   if (ABL == 3) {  // experiment: de-synchronise the CUs' epilogue bursts (odd workgroups start ~K/2 late)
@@ -695,7 +730,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   const int d_voff = ((wr * (RA0 + RA1) + fr) * ldd + wc * (RB0 + RB1)) * 2;  // bytes, within the tile
   auto epilogue = [&](int ti) {
     int tm, tn;
-    tile_of_block(bid + ti * G, ntiles, tiles_m, tiles_n, tm, tn);
+    tile_mn(ti, tm, tn);
     const int d_tile = (tm * TBM * ldd + tn * TBN) * 2;  // uniform, bytes
     float bv[2][2][4];
     if (BIAS) {  // this wave's own LDS-DMA data: covered by the vmcnt waits of the last K-tile, no barrier needed
@@ -765,19 +800,71 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
         }
   };
 
-  int kt = 0, ti = 0;
+  // SK: partial accumulators of slot `slot` (this wave's 32 KiB: [acc index][lane] x 16 B, whole 1-KiB lines per store)
+  const rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(SK ? (void*)sk_ws : (void*)A), 0, SK ? G * (8 * 32 * 1024) : 0, 0x00020000);
+  auto partial_store = [&](int slot) {
+    const int base = (slot * 8 + wave) * (32 * 1024);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < (a == 0 ? 4 : MA1); ++i)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int j = 0; j < (b == 0 ? 2 : NB1); ++j) {
+            const v4f v = acc[a][i][b][j];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mi::v4u, v), rsW, lane * 16, base + (((a * 4 + i) * 2 + b) * 2 + j) * 1024, 16);
+            asm volatile("s_nop 1" ::"v"(v) : "memory");
+            acc[a][i][b][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+          }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // write-through stores acknowledged (and the prefetches landed)
+    __builtin_amdgcn_s_barrier();  // wave group 1 passes this one only after group 0 passed its own (group 0 is a phase ahead)
+    if (wave == 4 && lane == 0) __hip_atomic_store(sk_flags + slot, sk_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto partial_add = [&](int slot) {
+    if (lane == 0) {
+      while (__hip_atomic_load(sk_flags + slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != sk_epoch) __builtin_amdgcn_s_sleep(8);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int base = (slot * 8 + wave) * (32 * 1024);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < (a == 0 ? 4 : MA1); ++i)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int j = 0; j < (b == 0 ? 2 : NB1); ++j) {
+            const mi::v4u w = __builtin_amdgcn_raw_buffer_load_b128(rsW, lane * 16, base + (((a * 4 + i) * 2 + b) * 2 + j) * 1024, 16);
+            acc[a][i][b][j] += __builtin_bit_cast(v4f, w);
+          }
+  };
+
+  int kt = SK ? sk_k0 : 0, ti = 0;
+  bool after = false;  // previous step ended with an epilogue whose stores are still in flight
   for (int pair = 0; pair < total / 2; ++pair) {
-    ktile(buf0, buf1, kt == 0 && ti > 0, 0);
+    ktile(buf0, buf1, after, 0);
     ktile(buf1, buf0, false, 1);
+    after = false;
     kt += 2;
     if (kt == nk) {
-      epilogue(ti);
+      if (SK && ti == 0 && sk_k0 != 0) {
+        partial_store(sk_v);
+      } else {
+        epilogue(ti);
+        after = true;
+      }
       kt = 0;
       ++ti;
     }
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (SK && kt != 0) {  // the range ended inside a tile: fetch the rest from the neighbour and finish it
+    partial_add(sk_v + 1);
+    epilogue(ti);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
 #undef MI_WAIT_SYNC
 #undef MI_PIN
 }
@@ -802,9 +889,9 @@ static int pick_tile_cfg(int64_t M, int64_t N, int64_t K) {
   const int ncu = num_cus();
   int best = -1;
   double best_cost = 0;
-  // Measured on MI355X (tools/bench_kernels.py --which tiles): the 192 shapes pay off when a round is long (K >= 4096);
-  // at K = 3072 their extra epilogues cost more than the half-empty last round of 256x256 tiles.
-  if (K < 4096 && M % 256 == 0 && N % 256 == 0) return 0;
+  // Measured on MI355X with interleaved A/B timing (tools/bench_kernels.py --which tiles; back-to-back timing is biased by
+  // clock drift): 8192x3072xK as 512 tiles of 256x192 beats 384 tiles of 256x256 by 5 % (K 3072) to 9 % (K 16384).
+  (void)K;
   for (int c = 0; c < 4; ++c) {
     if (M % bm[c] || N % bn[c]) continue;
     const int64_t tiles = (M / bm[c]) * (N / bn[c]);
@@ -818,6 +905,37 @@ static int pick_tile_cfg(int64_t M, int64_t N, int64_t K) {
   return best;
 }
 
+// stream-K workspace registered by the caller (mi_gemm_set_workspace): [4 KiB of flags][slots of 256 KiB]
+struct SkWorkspace {
+  unsigned int* flags = nullptr;
+  float* slots = nullptr;
+  int nslots = 0;
+};
+static SkWorkspace g_sk_ws[32];
+static std::atomic<unsigned int> g_sk_epoch{1};
+
+static const SkWorkspace* sk_workspace() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+  return g_sk_ws[dev].flags ? &g_sk_ws[dev] : nullptr;
+}
+
+// stream-K plan for 256x256 tiles: units per workgroup (0 = not applicable / not worth it)
+static int sk_units(int64_t M, int64_t N, int64_t K, bool force) {
+  if (M % 256 || N % 256 || K % 256) return 0;
+  const SkWorkspace* ws = sk_workspace();
+  const int ncu = num_cus();
+  if (!ws || ws->nslots < ncu) return 0;
+  const int64_t ntiles = (M / 256) * (N / 256), nk = K / BK;
+  if (ntiles <= ncu || ntiles % ncu == 0) return 0;
+  const int64_t rounds = (ntiles + ncu - 1) / ncu;
+  const double waste = 1.0 - (double)ntiles / (double)(rounds * ncu);
+  if (!force && waste < 0.06) return 0;
+  int64_t U = (ntiles * nk + ncu - 1) / ncu;
+  U += U & 1;
+  return U >= nk ? (int)U : 0;
+}
+
 template <int FA, int FB, bool MX, bool BIAS, int ABL, int MA1, int NB1>
 static void launch_p8_cfg(const uint8_t* a, const uint8_t* b, uint16_t* D, const float* sa_inv, const float* sb_inv,
                           const uint8_t* SA, const uint8_t* SB, const uint16_t* bias, int64_t M, int64_t N, int64_t K,
@@ -825,15 +943,52 @@ static void launch_p8_cfg(const uint8_t* a, const uint8_t* b, uint16_t* D, const
   constexpr int TBM = 2 * (64 + 16 * MA1), TBN = 4 * (32 + 16 * NB1);
   const int tiles_m = (int)(M / TBM), tiles_n = (int)(N / TBN);
   const int grid = tiles_m * tiles_n < num_cus() ? tiles_m * tiles_n : num_cus();
-  hipLaunchKernelGGL((gemm_256_p8<FA, FB, ABL, MX, BIAS, MA1, NB1>), dim3(grid), dim3(512), 0, st, a, b, D, sa_inv, sb_inv, (int)K,
+  hipLaunchKernelGGL((gemm_256_p8<FA, FB, ABL, MX, BIAS, MA1, NB1, false>), dim3(grid), dim3(512), 0, st, a, b, D, sa_inv, sb_inv, (int)K,
                      (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb), (int)(M * ldd * 2), SA, SB,
-                     (int)M, (int)N, bias);
+                     (int)M, (int)N, bias, (float*)nullptr, (unsigned int*)nullptr, 0u, 0);
+}
+
+template <int FA, int FB, bool MX, bool BIAS>
+static void launch_p8_sk(const uint8_t* a, const uint8_t* b, uint16_t* D, const float* sa_inv, const float* sb_inv,
+                         const uint8_t* SA, const uint8_t* SB, const uint16_t* bias, int64_t M, int64_t N, int64_t K,
+                         int64_t lda, int64_t ldb, int64_t ldd, int U, hipStream_t st) {
+  const int tiles_m = (int)(M / 256), tiles_n = (int)(N / 256);
+  const int64_t total = (int64_t)tiles_m * tiles_n * (K / BK);
+  const int grid = (int)((total + U - 1) / U);
+  const SkWorkspace* ws = sk_workspace();
+  const unsigned int epoch = g_sk_epoch.fetch_add(1);
+  hipLaunchKernelGGL((gemm_256_p8<FA, FB, 0, MX, BIAS, 4, 2, true>), dim3(grid), dim3(512), 0, st, a, b, D, sa_inv, sb_inv, (int)K,
+                     (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb), (int)(M * ldd * 2), SA, SB,
+                     (int)M, (int)N, bias, ws->slots, ws->flags, epoch == 0 ? g_sk_epoch.fetch_add(1) : epoch, U);
 }
 
 template <int FA, int FB>
 static int launch_p8(const uint8_t* a, const uint8_t* b, uint16_t* D, const float* sa_inv, const float* sb_inv,
                      const uint8_t* SA, const uint8_t* SB, const uint16_t* bias, int64_t M, int64_t N, int64_t K, int64_t lda,
                      int64_t ldb, int64_t ldd, int algo, bool mx, hipStream_t st) {
+  // algo 44: stream-K on 256x256 tiles (needs a registered workspace).  It is NOT part of the automatic choice: measured
+  // (interleaved A/B) it loses 3-15 % to the best whole-tile shape at K <= 8192 and wins 3.5 % only at K = 16384 -- the chip
+  // is power-limited, so a half-empty last round costs less than its CU count suggests (the busy CUs clock higher) while the
+  // partial-accumulator traffic is extra energy.  45 = the whole-tile picker (same as 4).
+  if (algo == 44) {
+    const int U = sk_units(M, N, K, algo == 44);
+    if (U > 0) {
+      if (mx) {
+        if (bias) launch_p8_sk<FA, FB, true, true>(a, b, D, sa_inv, sb_inv, SA, SB, bias, M, N, K, lda, ldb, ldd, U, st);
+        else launch_p8_sk<FA, FB, true, false>(a, b, D, sa_inv, sb_inv, SA, SB, bias, M, N, K, lda, ldb, ldd, U, st);
+      } else {
+        if (bias) launch_p8_sk<FA, FB, false, true>(a, b, D, sa_inv, sb_inv, SA, SB, bias, M, N, K, lda, ldb, ldd, U, st);
+        else launch_p8_sk<FA, FB, false, false>(a, b, D, sa_inv, sb_inv, SA, SB, bias, M, N, K, lda, ldb, ldd, U, st);
+      }
+      MI_CHECK_LAUNCH("mi_gemm (stream-K) launch");
+      return MI_OK;
+    }
+    if (algo == 44) {
+      set_error("mi_gemm: stream-K needs a registered workspace, 256-aligned M/N/K and more tiles than CUs (%lld x %lld x %lld)",
+                (long long)M, (long long)N, (long long)K);
+      return MI_ERR_SHAPE;
+    }
+  }
   int cfg = (algo >= 40 && algo <= 43) ? algo - 40 : pick_tile_cfg(M, N, K);
   static const int bm[4] = {256, 256, 192, 192}, bn[4] = {256, 192, 256, 192};
   if (cfg < 0 || M % bm[cfg] || N % bn[cfg]) {
@@ -880,7 +1035,7 @@ static int launch_fmt(const void* A, const void* B, void* D, const float* sa_inv
     int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
     hipLaunchKernelGGL((gemm_256_8ph<FA, FB, OUT>), dim3(tiles_m * tiles_n), dim3(512), 0, st, a, b, D, sa_inv, sb_inv,
                        bp, (int)M, (int)N, (int)K, lda, ldb, ldd, tiles_m, tiles_n);
-  } else if (algo == 4 || (algo >= 15 && algo <= 17) || (algo >= 40 && algo <= 43)) {
+  } else if (algo == 4 || (algo >= 15 && algo <= 17) || (algo >= 40 && algo <= 45)) {
     return launch_p8<FA, FB>(a, b, (uint16_t*)D, sa_inv, sb_inv, (const uint8_t*)SA, (const uint8_t*)SB, bp, M, N, K, lda, ldb, ldd,
                              algo, mx, st);
   } else if (algo == 13 && !mx) {
@@ -940,7 +1095,7 @@ static int pick_algo(int algo, int64_t M, int64_t N, int64_t K, int64_t lda, int
   const bool p8_ok = (M % 256 == 0 || M % 192 == 0) && (N % 256 == 0 || N % 192 == 0) && M > 0 && N > 0 && K > 0 &&
                      (K % (2 * BK) == 0) && out == 0 && M * lda < (1LL << 31) && N * ldb < (1LL << 31) &&
                      M * ldd * 2 < (1LL << 31);
-  if (algo == 4 || (algo >= 15 && algo <= 17) || (algo >= 40 && algo <= 43)) {
+  if (algo == 4 || (algo >= 15 && algo <= 17) || (algo >= 40 && algo <= 45)) {
     if (!p8_ok) {
       set_error("%s: algo %d needs M,N %% 256 (or 192) == 0, K %% 256 == 0, bf16 output, operands < 2 GiB", who, algo);
       return MI_ERR_SHAPE;
@@ -982,7 +1137,7 @@ extern "C" int mi_gemm_mxfp8(const void* A, const void* SA, const void* B, const
   if (rc != MI_OK) return rc;
   MI_CHECK_ARG(SA && SB, "mi_gemm_mxfp8: null scale pointer");
   MI_CHECK_ARG(K % 32 == 0, "mi_gemm_mxfp8: K must be a multiple of 32");
-  MI_CHECK_ARG(algo == 0 || algo == 1 || algo == 4 || (algo >= 40 && algo <= 43), "mi_gemm_mxfp8: algo must be 0, 1, 4 or 40-43");
+  MI_CHECK_ARG(algo == 0 || algo == 1 || algo == 4 || (algo >= 40 && algo <= 45), "mi_gemm_mxfp8: algo must be 0, 1, 4 or 40-45");
   if (M == 0 || N == 0) return MI_OK;
   int a = algo == 0 ? 4 : algo;
   if (a != 1) {
@@ -994,4 +1149,27 @@ extern "C" int mi_gemm_mxfp8(const void* A, const void* SA, const void* B, const
   }
   return mi::dispatch(A, B, D, nullptr, nullptr, SA, SB, bias_bf16, M, N, K, K, K, N, fmt_a, fmt_b, out_dtype, a, true,
                       (hipStream_t)stream);
+}
+
+extern "C" int64_t mi_gemm_workspace_bytes(void) { return 4096 + (int64_t)mi::num_cus() * (8 * 32 * 1024); }
+
+extern "C" int mi_gemm_set_workspace(void* workspace, int64_t bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) {
+    mi::set_error("mi_gemm_set_workspace: no current device");
+    return MI_ERR_HIP;
+  }
+  if (workspace == nullptr) {
+    mi::g_sk_ws[dev] = mi::SkWorkspace();
+    return MI_OK;
+  }
+  MI_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "mi_gemm_set_workspace: pointer must be 256-byte aligned");
+  MI_CHECK_ARG(bytes >= 4096 + 8 * 32 * 1024, "mi_gemm_set_workspace: %lld bytes is too small", (long long)bytes);
+  mi::SkWorkspace w;
+  w.flags = (unsigned int*)workspace;
+  w.slots = (float*)((char*)workspace + 4096);
+  w.nslots = (int)((bytes - 4096) / (8 * 32 * 1024));
+  if (w.nslots > 1024) w.nslots = 1024;
+  mi::g_sk_ws[dev] = w;
+  return MI_OK;
 }

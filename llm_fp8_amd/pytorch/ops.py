@@ -14,6 +14,24 @@ E4M3, E5M2 = _lib.MI_FMT_E4M3, _lib.MI_FMT_E5M2
 FP8_MAX = {E4M3: 448.0, E5M2: 57344.0}
 
 
+_SK_WORKSPACE = {}
+
+
+def ensure_gemm_workspace(device: torch.device) -> None:
+    """Registers the stream-K workspace of mi_gemm_fp8 / mi_gemm_mxfp8 for `device` (allocated once, zeroed flags; owned here).
+    Only the explicit algo 44 uses it (stream-K measured slower than the whole-tile shapes at the reference's sizes)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx in _SK_WORKSPACE:
+        return
+    lib = _lib.load()
+    with torch.cuda.device(idx):
+        nbytes = int(lib.mi_gemm_workspace_bytes())
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=torch.device("cuda", idx))
+        torch.cuda.synchronize(idx)
+        _lib.check(lib.mi_gemm_set_workspace(ws.data_ptr(), nbytes), "mi_gemm_set_workspace")
+    _SK_WORKSPACE[idx] = ws
+
+
 def default_gemm_algo() -> int:
     """0 (auto: persistent kernel) on a single GPU.  Under torch.distributed with more than one rank the non-persistent
     8-phase kernel (3): RCCL's collectives overlap the GEMMs under FSDP / DDP and hold some CUs; a persistent grid with
@@ -98,6 +116,8 @@ def gemm_fp8(a8: torch.Tensor, b8: torch.Tensor, sa_inv: torch.Tensor, sb_inv: t
         if algo == 3 and (a8.shape[0] % 256 or b8.shape[0] % 256 or a8.shape[1] % 128):
             algo = 0
     _dev(a8, b8, sa_inv, sb_inv, bias, out)
+    if algo == 44:
+        ensure_gemm_workspace(a8.device)
     assert a8.dtype == torch.uint8 and b8.dtype == torch.uint8 and a8.dim() == 2 and b8.dim() == 2
     assert a8.stride(1) == 1 and b8.stride(1) == 1
     M, K = a8.shape
@@ -150,6 +170,8 @@ def gemm_mxfp8(a8, sa, b8, sb, fmt_a: int = E4M3, fmt_b: int = E4M3, bias=None, 
                out_dtype: torch.dtype = torch.bfloat16, algo: int = 0) -> torch.Tensor:
     """K8.  Block-scaled D[M,N] = sum_blk 2^(sa+sb-254) sum_32 A.B (+bias)."""
     _dev(a8, sa, b8, sb, bias, out)
+    if algo == 44:
+        ensure_gemm_workspace(a8.device)
     M, K = a8.shape
     N, K2 = b8.shape
     assert K == K2 and a8.is_contiguous() and b8.is_contiguous() and sa.is_contiguous() and sb.is_contiguous()

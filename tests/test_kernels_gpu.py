@@ -528,3 +528,41 @@ def test_attn_bwd_full_size_vs_torch_autograd_and_reproducible(ops, dev):
     for got, ref, name in ((dq, qr.grad, "dq"), (dk, kr.grad, "dk"), (dv, vr.grad, "dv")):
         rel = ((got.float() - ref).norm() / ref.norm()).item()
         assert rel < 6e-3, f"{name}: {rel:.4g}"
+
+
+@pytest.mark.parametrize("shape", [(8192, 3072, 512), (4352, 4096, 768), (8192, 5120, 256), (2560, 8192, 1024)])
+@pytest.mark.parametrize("fa,fb", [(O.E4M3, O.E4M3), (O.E5M2, O.E4M3)])
+def test_gemm_streamk_vs_oracle(ops, dev, shape, fa, fb):
+    """Stream-K form of the persistent kernel (algo 44): tiles split between two workgroups are summed through the
+    registered workspace; checked against the oracle, with and without bias, twice (flag epochs), and against whole tiles."""
+    M, N, K = shape
+    a8 = _rand_fp8((M, K), fa, 11 + M, 4.0 if fa == O.E4M3 else 64.0)
+    b8 = _rand_fp8((N, K), fb, 12 + N, 4.0)
+    sa, sb = np.float32(1 / 3.1), np.float32(1 / 0.02)
+    bias = O.f32_to_bf16_bits(np.random.default_rng(4).normal(size=N).astype(np.float32) * 10)
+    ta, tb = torch.from_numpy(a8).to(dev), torch.from_numpy(b8).to(dev)
+    # 2^-7 |ref| + 1e-3 rms (bf16 output) plus the MFMA in-instruction truncation bound (see assert_mfma_close)
+    mag = (np.abs(O.fp8_decode(a8, fa)).astype(np.float64) @ np.abs(O.fp8_decode(b8, fb)).astype(np.float64).T) * float(sa) * float(sb)
+    for use_bias in (False, True, False):
+        ref = O.gemm_fp8_tn(a8, b8, fa, fb, sa, sb, bias if use_bias else None, out_f32=True)
+        d = ops.gemm_fp8(ta, tb, _f32(sa, dev), _f32(sb, dev), fa, fb, bias=bits_to_bf16(bias, dev) if use_bias else None, algo=44)
+        diff = np.abs(d.float().cpu().numpy().astype(np.float64) - ref)
+        bad = diff > O.gemm_tolerance(ref) + 7 * 2.0 ** -14 * mag
+        assert not bad.any(), f"stream-K {shape} bias {use_bias}: {bad.sum()} outside tolerance, max diff {diff.max():.4g}"
+    whole = ops.gemm_fp8(ta, tb, _f32(sa, dev), _f32(sb, dev), fa, fb, algo=45)
+    diff = (d.float() - whole.float()).abs()
+    assert (diff <= 2 ** -6 * whole.float().abs() + 1e-6).all()  # a bf16 ulp or two from the different summation order
+
+
+def test_gemm_mxfp8_streamk_vs_oracle(ops, dev):
+    M, N, K = 4352, 4096, 512
+    g = torch.Generator().manual_seed(9)
+    a = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, K // 32, generator=g).repeat_interleave(32, 1))).to(torch.bfloat16)
+    b = (torch.randn(N, K, generator=g) * torch.exp(torch.randn(N, K // 32, generator=g).repeat_interleave(32, 1))).to(torch.bfloat16)
+    a8, ae = O.mxfp8_quantize_rowwise(bf16_bits(a))
+    b8, be = O.mxfp8_quantize_rowwise(bf16_bits(b))
+    ref = O.gemm_mxfp8_tn(a8, ae, b8, be, out_f32=True)
+    t = lambda v: torch.from_numpy(v).to(dev)
+    tT = lambda v: torch.from_numpy(np.ascontiguousarray(v.T)).to(dev)
+    d = ops.gemm_mxfp8(t(a8), tT(ae), t(b8), tT(be), algo=44)
+    assert_gemm_close(d.float().cpu().numpy(), ref, "mx stream-K")

@@ -24,6 +24,27 @@ def time_fn(fn, iters=20, warmup=5):
     return s.elapsed_time(e) / iters * 1e-3
 
 
+def time_interleaved(fns, rounds=12, inner=4, warmup=2):
+    """A/B timing that is fair under clock/thermal drift: every round runs each candidate `inner` times, in rotating order."""
+    keys = list(fns)
+    for k in keys:
+        for _ in range(warmup):
+            fns[k]()
+    torch.cuda.synchronize()
+    tot = {k: 0.0 for k in keys}
+    for r in range(rounds):
+        order = keys[r % len(keys):] + keys[:r % len(keys)]
+        for k in order:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(inner):
+                fns[k]()
+            e.record()
+            torch.cuda.synchronize()
+            tot[k] += s.elapsed_time(e) * 1e-3
+    return {k: tot[k] / (rounds * inner) for k in keys}
+
+
 def rand_fp8(shape, dev, g):
     t = torch.randint(0, 256, shape, generator=g, device=dev, dtype=torch.uint8)
     t[(t & 0x7F) >= 0x78] &= 0x3F  # keep |v| modest, no NaN
@@ -51,17 +72,17 @@ def main():
                           f"({tf/5000*100:5.1f}% of 5 PF)", flush=True)
     if "tiles" in args.which:
         for (m, n, k) in ((8192, 3072, 3072), (8192, 3072, 8192), (3072, 8192, 8192), (3072, 3072, 8192), (8192, 3072, 16384),
-                          (8192, 6144, 3072), (6144, 6144, 4096)):
+                          (8192, 6144, 3072), (6144, 6144, 4096), (8192, 3072, 5120), (8192, 5120, 3072), (5120, 3072, 8192)):
             a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
             out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
-            for algo in (40, 41, 42, 43, 4):
-                bm, bn = {40: (256, 256), 41: (256, 192), 42: (192, 256), 43: (192, 192), 4: (1, 1)}[algo]
-                if m % bm or n % bn:
+            fns = {}
+            for algo in (40, 41, 42, 43, 44):
+                bm, bn = {40: (256, 256), 41: (256, 192), 42: (192, 256), 43: (192, 192), 44: (256, 256)}[algo]
+                if m % bm or n % bn or (algo == 44 and ((m // 256) * (n // 256) <= 256 or (m // 256) * (n // 256) % 256 == 0)):
                     continue
-                t = time_fn(lambda: ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=algo), args.iters)
-                tiles = (m // bm) * (n // bn) if algo != 4 else 0
-                print(f"tiles {m}x{n}x{k} algo {algo} ({bm}x{bn}, {tiles} tiles = {tiles/256:.2f} rounds): {t*1e6:8.1f} us "
-                      f"{2.0*m*n*k/t/1e12:7.1f} TFLOP/s", flush=True)
+                fns[algo] = (lambda al: (lambda: ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=al)))(algo)
+            res = time_interleaved(fns)
+            print(f"tiles {m}x{n}x{k}: " + "  ".join(f"algo {al}: {t*1e6:7.1f} us {2.0*m*n*k/t/1e12:6.0f} TF" for al, t in res.items()), flush=True)
     if "mxgemm" in args.which:
         for name, (M, N, K) in SHAPES_3B.items():
             for kind, (m, n, k) in (("fprop", (M, N, K)), ("dgrad", (M, K, N)), ("wgrad", (N, K, M))):
