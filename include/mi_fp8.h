@@ -41,6 +41,9 @@ extern "C" {
 #define MI_ERR_SHAPE (-2)
 #define MI_ERR_HIP (-3)
 
+#define MI_OUT_BF16 0
+#define MI_OUT_F32 1
+
 #define MI_AMAX_ALGO_MAX 0
 #define MI_AMAX_ALGO_MOST_RECENT 1
 
@@ -61,6 +64,16 @@ int mi_device_supported(void);
  */
 int mi_cast_amax(const void* x_bf16, void* y_fp8, void* yT_fp8, const float* scale, float* amax,
                  int64_t rows, int64_t cols, int64_t ld_y, int64_t ld_yT, int fmt, void* stream);
+/*
+ * mi_cast_amax that also returns the column sums of x (the bias gradient when x = grad_output of a Linear,
+ * `db = sum_M dy`): colsum_partial [ceil(rows/128), cols] fp32, one row per 128-row tile, to be reduced by
+ * mi_colsum_finish.  Fixed summation order: reproducible.
+ */
+int mi_cast_amax_colsum(const void* x_bf16, void* y_fp8, void* yT_fp8, const float* scale, float* amax,
+                        float* colsum_partial, int64_t rows, int64_t cols, int64_t ld_y, int64_t ld_yT, int fmt, void* stream);
+/* out[c] = sum_p partial[p, c]; out bf16 (MI_OUT_BF16) or fp32 (MI_OUT_F32).  Second stage of every partial column sum
+ * the library emits (mi_cast_amax_colsum, mi_dswiglu_cast, mi_mxfp8_dswiglu_quantize, mi_rmsnorm_bwd). */
+int mi_colsum_finish(const float* partial, int64_t P, int64_t C, void* out, int out_dtype, void* stream);
 
 /*
  * K3  amax-history roll + scale update for S slots in ONE launch

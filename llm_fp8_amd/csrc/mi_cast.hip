@@ -15,12 +15,16 @@
 
 namespace mi {
 
-template <int FMT, bool WRITE_Y, bool WRITE_T>
+// COLSUM: also emits colsum[tile_r, c] = sum of the tile's (up to) 128 rows of x[:, c] in fp32 -- the bias gradient of a
+// Linear comes out of the cast of its grad_output instead of a separate reduction pass over dy.
+template <int FMT, bool WRITE_Y, bool WRITE_T, bool COLSUM = false>
 __global__ __launch_bounds__(256) void cast_amax_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ y,
                                                         uint8_t* __restrict__ yT, const float* __restrict__ scale_p,
                                                         float* amax_out, int rows, int cols, int64_t ld_y,
-                                                        int64_t ld_yT, int tiles_c) {
+                                                        int64_t ld_yT, int tiles_c, float* __restrict__ colsum = nullptr) {
   __shared__ float s_amax[4];
+  __shared__ float s_cs[COLSUM ? 4 * 64 : 1];
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile_r = blockIdx.x / tiles_c, tile_c = blockIdx.x % tiles_c;
   const int r0 = tile_r * 128 + (wave >> 1) * 64 + (lane >> 3) * 8;
@@ -56,6 +60,10 @@ __global__ __launch_bounds__(256) void cast_amax_kernel(const uint16_t* __restri
 #pragma unroll
         for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(f[j]));
       }
+      if (COLSUM) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cs[j] += f[j];
+      }
       lo[i] = cvt4_fp8<FMT>(f[0] * scale, f[1] * scale, f[2] * scale, f[3] * scale);
       hi[i] = cvt4_fp8<FMT>(f[4] * scale, f[5] * scale, f[6] * scale, f[7] * scale);
     }
@@ -78,6 +86,23 @@ __global__ __launch_bounds__(256) void cast_amax_kernel(const uint16_t* __restri
       }
     }
   }
+  if (COLSUM) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      cs[j] += __shfl_xor(cs[j], 8);
+      cs[j] += __shfl_xor(cs[j], 16);
+      cs[j] += __shfl_xor(cs[j], 32);
+    }
+    if (lane < 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s_cs[wave * 64 + lane * 8 + j] = cs[j];
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int c = tile_c * 128 + tid;
+      if (c < cols) colsum[(int64_t)tile_r * cols + c] = s_cs[(tid >> 6) * 64 + (tid & 63)] + s_cs[(2 + (tid >> 6)) * 64 + (tid & 63)];
+    }
+  }
   if (amax_out != nullptr) {
     amax = wave_max(amax);
     if (lane == 0) s_amax[wave] = amax;
@@ -89,30 +114,72 @@ __global__ __launch_bounds__(256) void cast_amax_kernel(const uint16_t* __restri
   }
 }
 
+// second stage of every [P, C] fp32 partial column sum (cast, dSwiGLU, RMSNorm backward): out[c] = sum_p part[p, c]
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int P, int C, void* __restrict__ out,
+                                                            int out_bf16) {
+  // 32 columns x 8 row-groups per workgroup: 128-byte row segments, 8 independent accumulation chains per column
+  __shared__ float s_acc[8][32];
+  const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+  if (c < C) {
+    int p = py;
+    for (; p + 24 < P; p += 32) {
+      a0 += part[(int64_t)p * C + c];
+      a1 += part[(int64_t)(p + 8) * C + c];
+      a2 += part[(int64_t)(p + 16) * C + c];
+      a3 += part[(int64_t)(p + 24) * C + c];
+    }
+    for (; p < P; p += 8) a0 += part[(int64_t)p * C + c];
+  }
+  s_acc[py][cx] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (py == 0 && c < C) {
+    float a = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a += s_acc[i][cx];
+    if (out_bf16) reinterpret_cast<uint16_t*>(out)[c] = (uint16_t)float_to_bf16_bits(a);
+    else reinterpret_cast<float*>(out)[c] = a;
+  }
+}
+
 template <int FMT>
 static int launch_cast(const void* x, void* y, void* yT, const float* scale, float* amax, int64_t rows,
-                       int64_t cols, int64_t ld_y, int64_t ld_yT, hipStream_t st) {
+                       int64_t cols, int64_t ld_y, int64_t ld_yT, hipStream_t st, float* colsum = nullptr) {
   const int tiles_r = (int)((rows + 127) / 128), tiles_c = (int)((cols + 127) / 128);
   dim3 grid((unsigned)(tiles_r * tiles_c)), block(256);
   const uint16_t* xp = (const uint16_t*)x;
   uint8_t *yp = (uint8_t*)y, *tp = (uint8_t*)yT;
+  if (colsum) {
+    if (y && yT)
+      hipLaunchKernelGGL((cast_amax_kernel<FMT, true, true, true>), grid, block, 0, st, xp, yp, tp, scale, amax, (int)rows,
+                         (int)cols, ld_y, ld_yT, tiles_c, colsum);
+    else if (y)
+      hipLaunchKernelGGL((cast_amax_kernel<FMT, true, false, true>), grid, block, 0, st, xp, yp, tp, scale, amax, (int)rows,
+                         (int)cols, ld_y, ld_yT, tiles_c, colsum);
+    else
+      hipLaunchKernelGGL((cast_amax_kernel<FMT, false, true, true>), grid, block, 0, st, xp, yp, tp, scale, amax, (int)rows,
+                         (int)cols, ld_y, ld_yT, tiles_c, colsum);
+    MI_CHECK_LAUNCH("mi_cast_amax_colsum launch");
+    return MI_OK;
+  }
   if (y && yT)
     hipLaunchKernelGGL((cast_amax_kernel<FMT, true, true>), grid, block, 0, st, xp, yp, tp, scale, amax, (int)rows,
-                       (int)cols, ld_y, ld_yT, tiles_c);
+                       (int)cols, ld_y, ld_yT, tiles_c, (float*)nullptr);
   else if (y)
     hipLaunchKernelGGL((cast_amax_kernel<FMT, true, false>), grid, block, 0, st, xp, yp, tp, scale, amax, (int)rows,
-                       (int)cols, ld_y, ld_yT, tiles_c);
+                       (int)cols, ld_y, ld_yT, tiles_c, (float*)nullptr);
   else
     hipLaunchKernelGGL((cast_amax_kernel<FMT, false, true>), grid, block, 0, st, xp, yp, tp, scale, amax, (int)rows,
-                       (int)cols, ld_y, ld_yT, tiles_c);
+                       (int)cols, ld_y, ld_yT, tiles_c, (float*)nullptr);
   MI_CHECK_LAUNCH("mi_cast_amax launch");
   return MI_OK;
 }
 
 }  // namespace mi
 
-extern "C" int mi_cast_amax(const void* x_bf16, void* y_fp8, void* yT_fp8, const float* scale, float* amax,
-                            int64_t rows, int64_t cols, int64_t ld_y, int64_t ld_yT, int fmt, void* stream) {
+static int cast_amax_impl(const void* x_bf16, void* y_fp8, void* yT_fp8, const float* scale, float* amax,
+                          int64_t rows, int64_t cols, int64_t ld_y, int64_t ld_yT, int fmt, void* stream, float* colsum) {
   MI_CHECK_ARG(x_bf16 && scale, "mi_cast_amax: x and scale must be non-null");
   MI_CHECK_ARG(y_fp8 || yT_fp8, "mi_cast_amax: at least one of y, yT must be non-null");
   MI_CHECK_ARG(rows >= 0 && cols >= 0, "mi_cast_amax: negative shape");
@@ -127,6 +194,28 @@ extern "C" int mi_cast_amax(const void* x_bf16, void* y_fp8, void* yT_fp8, const
   MI_CHECK_ARG(fmt == MI_FMT_E4M3 || fmt == MI_FMT_E5M2, "mi_cast_amax: bad fmt %d", fmt);
   if (rows == 0 || cols == 0) return MI_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (fmt == MI_FMT_E4M3) return mi::launch_cast<MI_FMT_E4M3>(x_bf16, y_fp8, yT_fp8, scale, amax, rows, cols, ld_y, ld_yT, st);
-  return mi::launch_cast<MI_FMT_E5M2>(x_bf16, y_fp8, yT_fp8, scale, amax, rows, cols, ld_y, ld_yT, st);
+  if (fmt == MI_FMT_E4M3) return mi::launch_cast<MI_FMT_E4M3>(x_bf16, y_fp8, yT_fp8, scale, amax, rows, cols, ld_y, ld_yT, st, colsum);
+  return mi::launch_cast<MI_FMT_E5M2>(x_bf16, y_fp8, yT_fp8, scale, amax, rows, cols, ld_y, ld_yT, st, colsum);
+}
+
+extern "C" int mi_cast_amax(const void* x_bf16, void* y_fp8, void* yT_fp8, const float* scale, float* amax,
+                            int64_t rows, int64_t cols, int64_t ld_y, int64_t ld_yT, int fmt, void* stream) {
+  return cast_amax_impl(x_bf16, y_fp8, yT_fp8, scale, amax, rows, cols, ld_y, ld_yT, fmt, stream, nullptr);
+}
+
+extern "C" int mi_cast_amax_colsum(const void* x_bf16, void* y_fp8, void* yT_fp8, const float* scale, float* amax,
+                                   float* colsum_partial, int64_t rows, int64_t cols, int64_t ld_y, int64_t ld_yT, int fmt,
+                                   void* stream) {
+  MI_CHECK_ARG(colsum_partial, "mi_cast_amax_colsum: colsum_partial must be non-null");
+  return cast_amax_impl(x_bf16, y_fp8, yT_fp8, scale, amax, rows, cols, ld_y, ld_yT, fmt, stream, colsum_partial);
+}
+
+extern "C" int mi_colsum_finish(const float* partial, int64_t P, int64_t C, void* out, int out_dtype, void* stream) {
+  MI_CHECK_ARG(partial && out, "mi_colsum_finish: null pointer");
+  MI_CHECK_ARG(P >= 1 && P < (1 << 24) && C >= 1 && C < (1LL << 31), "mi_colsum_finish: bad shape");
+  MI_CHECK_ARG(out_dtype == MI_OUT_BF16 || out_dtype == MI_OUT_F32, "mi_colsum_finish: bad out_dtype %d", out_dtype);
+  hipLaunchKernelGGL(mi::colsum_finish_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, (hipStream_t)stream, partial,
+                     (int)P, (int)C, out, out_dtype == MI_OUT_BF16 ? 1 : 0);
+  MI_CHECK_LAUNCH("mi_colsum_finish launch");
+  return MI_OK;
 }

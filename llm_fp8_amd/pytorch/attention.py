@@ -198,8 +198,17 @@ class MultiheadAttention(torch.nn.Module):
                            init_method=output_layer_init_method or init_method)
 
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
-                rotary_pos_emb=None, **_ignored) -> torch.Tensor:
+                rotary_pos_emb=None, _with_skip: bool = False, **_ignored):
+        """`_with_skip` (extension): returns (out, skip), see LayerNormLinear.forward."""
+        if _with_skip:
+            if not self.input_layernorm:
+                return self._attend(self.qkv(hidden_states), attention_mask, rotary_pos_emb), hidden_states
+            qkv, skip = self.layernorm_qkv(hidden_states, _with_skip=True)
+            return self._attend(qkv, attention_mask, rotary_pos_emb), skip
         qkv = self.layernorm_qkv(hidden_states) if self.input_layernorm else self.qkv(hidden_states)
+        return self._attend(qkv, attention_mask, rotary_pos_emb)
+
+    def _attend(self, qkv: torch.Tensor, attention_mask, rotary_pos_emb) -> torch.Tensor:
         if (rotary_pos_emb is not None and not isinstance(rotary_pos_emb, (tuple, list)) and qkv.is_cuda
                 and qkv.dtype == torch.bfloat16 and self.qkv_format == "bshd" and self.d % 16 == 0
                 and rotary_pos_emb.shape[-1] == self.d):

@@ -62,6 +62,7 @@ class MetaArena:
         self.used = 0
         self.reduce_amax = True
         self.group = None
+        self._snap: Optional[torch.Tensor] = None  # copy of scale_inv taken at most once between two updates
 
     def alloc(self, n: int) -> int:
         if self.used + n > self.CAP:
@@ -80,10 +81,18 @@ class MetaArena:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             dist.all_reduce(self.hist[0, :n], op=dist.ReduceOp.MAX, group=self.group)
 
+    def snapshot(self) -> torch.Tensor:
+        """scale_inv as of now, as ONE device copy shared by every module of the arena until the next update.  Autograd
+        Functions keep views of it for their backward (the arena itself is rewritten at autocast exit, before backward)."""
+        if self._snap is None or self._snap.numel() < self.used:
+            self._snap = self.scale_inv[:self.CAP if self.used == 0 else self.used].clone()
+        return self._snap
+
     def update(self) -> None:
         if self.used == 0:
             return
         n = self.used
+        self._snap = None
         self.reduce()
         ops.scale_update(self.hist[:, :n], self.scale[:n], self.scale_inv[:n], self.fp8_max[:n], self.margin, self.algo)
 
@@ -104,7 +113,8 @@ class ModuleMeta:
         return self.arena.hist[0, self.start + i:self.start + i + 1]
 
     def scale_inv_snapshot(self) -> torch.Tensor:
-        return self.arena.scale_inv[self.start:self.start + self.n].clone()
+        """Read-only view [n] of the arena's snapshot (do not write into it: it is shared)."""
+        return self.arena.snapshot()[self.start:self.start + self.n]
 
     def state(self) -> Dict[str, torch.Tensor]:
         a, s, n = self.arena, self.start, self.n
@@ -113,6 +123,7 @@ class ModuleMeta:
 
     def load_state(self, st: Dict[str, torch.Tensor]) -> None:
         a, s, n = self.arena, self.start, self.n
+        a._snap = None
         a.scale[s:s + n].copy_(st["scale"])
         a.scale_inv[s:s + n].copy_(st["scale_inv"])
         h = st["amax_history"]

@@ -37,10 +37,14 @@ def _as_bf16_2d(t: torch.Tensor) -> torch.Tensor:
 class _GemmSpec:
     """Everything non-tensor a GEMM site needs: recipe, meta windows, slot base, update trigger."""
     __slots__ = ("recipe", "meta_fwd", "meta_bwd", "g", "fmt_fwd", "fmt_bwd", "trigger_bwd_update", "training", "eps",
-                 "wcache", "first_mb")
+                 "wcache", "first_mb", "with_skip")
 
-    def __init__(self, recipe, meta_fwd, meta_bwd, g, trigger_bwd_update, training, eps=1e-5, wcache=None, first_mb=None):
+    def __init__(self, recipe, meta_fwd, meta_bwd, g, trigger_bwd_update, training, eps=1e-5, wcache=None, first_mb=None,
+                 with_skip=False):
         self.eps = eps
+        # with_skip: the Function also returns its input as a second output (the residual branch); the gradient arriving
+        # over it is added inside the RMSNorm-backward kernel instead of by a separate autograd add
+        self.with_skip = with_skip
         # FP8 weight caching across micro-batches (TE `is_first_microbatch`, SURVEY.md 8f rank 3): None = cast every
         # forward (what the reference does), True = cast and keep, False = reuse the kept FP8 weights and their scale_inv
         self.wcache, self.first_mb = wcache, first_mb
@@ -69,11 +73,18 @@ def _cast_weights(spec: _GemmSpec, g: int, weights, ns, N: int, K: int, dev, nee
         ops.cast_amax(wb.contiguous(), mf.scale(3 * g + 1), mf.amax(3 * g + 1), spec.fmt_fwd,
                       y=w8[r:r + n], yT=None if w8t is None else w8t[:, r:r + n], want_t=want_t)
         r += n
-    siw = mf.scale_inv(3 * g + 1)
+    siw = mf.scale_inv_snapshot()[3 * g + 1:3 * g + 2]  # the arena is rewritten at autocast exit; the snapshot is not
     if keep:
-        siw = siw.clone()
         spec.wcache[ck] = (w8, w8t, siw)
     return w8, w8t, siw
+
+
+def _skip_2d(dskip: Optional[torch.Tensor], like: torch.Tensor) -> Optional[torch.Tensor]:
+    """Residual-branch gradient as a contiguous bf16 [tokens, features] matrix for mi_rmsnorm_bwd's `dres`."""
+    if dskip is None:
+        return None
+    d = dskip.reshape(like.shape)
+    return d if (d.dtype == torch.bfloat16 and d.is_contiguous()) else d.to(torch.bfloat16).contiguous()
 
 
 class _FP8LinearFn(torch.autograd.Function):
@@ -130,24 +141,25 @@ class _FP8LinearFn(torch.autograd.Function):
             w8, w8t, siw = _cast_weights(spec, g, weights, ns, N, K, dev, need_dgrad)
             y = ops.gemm_fp8(x8, w8, mf.scale_inv(3 * g), siw, spec.fmt_fwd, spec.fmt_fwd, bias=bias_bf16)
             # scale_inv as of quantisation time: the arena is updated at autocast exit, before backward
-            sinv = mf.scale_inv_snapshot() if (need_wgrad or need_dgrad) else None
-            if sinv is not None:
-                sinv[3 * g + 1:3 * g + 2].copy_(siw)
+            sinv = (mf.scale_inv_snapshot()[3 * g:3 * g + 1], siw) if (need_wgrad or need_dgrad) else None
             ctx.saved_fp8 = (x8t, None, w8t, None, sinv)
         ctx.spec, ctx.ns, ctx.x_shape, ctx.x_dtype = spec, ns, x.shape, x.dtype
         ctx.w_dtypes = [w.dtype for w in weights]
         ctx.has_bias, ctx.bias_dtype = bias is not None, (None if bias is None else bias.dtype)
         ctx.need_wgrad, ctx.need_dgrad = need_wgrad, need_dgrad
+        if spec.with_skip:
+            ctx.set_materialize_grads(False)
+            return y.view(*x.shape[:-1], N), x
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
-    def backward(ctx, dy: torch.Tensor):
+    def backward(ctx, dy: torch.Tensor, dskip: Optional[torch.Tensor] = None):
         spec = ctx.spec
         g2 = _as_bf16_2d(dy)
         M, N = g2.shape
         xt8, xts, wt8, wts, sinv = ctx.saved_fp8
         ctx.saved_fp8 = None
-        dx = dw = None
+        dx = dw = db_fused = None
         if spec.recipe.mxfp8():
             g8, gs, gt8, gts = ops.mxfp8_quantize(g2, spec.fmt_bwd, rowwise=ctx.need_dgrad, colwise=ctx.need_wgrad)
             if ctx.need_dgrad:
@@ -156,27 +168,34 @@ class _FP8LinearFn(torch.autograd.Function):
                 dw = ops.gemm_mxfp8(gt8, gts, xt8, xts, spec.fmt_bwd, spec.fmt_fwd)
         else:
             mb, g = spec.meta_bwd, spec.g
-            g8, g8t = ops.cast_amax(g2, mb.scale(2 * g), mb.amax(2 * g), spec.fmt_bwd,
-                                    want_y=ctx.need_dgrad, want_t=ctx.need_wgrad)
+            if ctx.has_bias:  # the bias gradient rides on the cast of dy
+                g8, g8t, cs = ops.cast_amax(g2, mb.scale(2 * g), mb.amax(2 * g), spec.fmt_bwd,
+                                            want_y=ctx.need_dgrad, want_t=ctx.need_wgrad, want_colsum=True)
+                db_fused = ops.colsum_finish(cs, ctx.bias_dtype)
+            else:
+                g8, g8t = ops.cast_amax(g2, mb.scale(2 * g), mb.amax(2 * g), spec.fmt_bwd,
+                                        want_y=ctx.need_dgrad, want_t=ctx.need_wgrad)
             sig = mb.scale_inv(2 * g)
             if ctx.need_dgrad:
-                dx = ops.gemm_fp8(g8, wt8, sig, sinv[3 * g + 1:3 * g + 2], spec.fmt_bwd, spec.fmt_fwd)
+                dx = ops.gemm_fp8(g8, wt8, sig, sinv[1], spec.fmt_bwd, spec.fmt_fwd)
             if ctx.need_wgrad:
-                dw = ops.gemm_fp8(g8t, xt8, sig, sinv[3 * g:3 * g + 1], spec.fmt_bwd, spec.fmt_fwd)
+                dw = ops.gemm_fp8(g8t, xt8, sig, sinv[0], spec.fmt_bwd, spec.fmt_fwd)
         db = None
         if ctx.has_bias:
-            db = g2.sum(0, dtype=torch.float32).to(ctx.bias_dtype)
+            db = db_fused if db_fused is not None else g2.sum(0, dtype=torch.float32).to(ctx.bias_dtype)
         dln = None
         if ctx.norm is not None and dx is not None:
             xin, rstd, gam, ln_dtype = ctx.norm
             ctx.norm = None
-            dx, dgam = ops.rmsnorm_bwd(dx, xin, rstd, gam)
-            dln = dgam.to(ln_dtype)
+            dx, dln = ops.rmsnorm_bwd(dx, xin, rstd, gam, dres=_skip_2d(dskip, dx), dgamma_dtype=ln_dtype)
+            dskip = None
         if spec.trigger_bwd_update:
             # this GEMM belongs to the first FP8 module of the outermost autocast: its backward is the last
             FP8GlobalStateManager.reduce_and_update_fp8_tensors(forward=False)
         if dx is not None:
             dx = dx.view(ctx.x_shape).to(ctx.x_dtype)
+        if dskip is not None:
+            dx = dskip if dx is None else dx + dskip
         dws: List[Optional[torch.Tensor]] = [None] * len(ctx.ns)
         if dw is not None:
             parts = torch.split(dw, ctx.ns, dim=0)
@@ -221,14 +240,15 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
         w2_8, w2_8t, si2 = _cast_weights(spec, 1, (w2,), [w2.shape[0]], w2.shape[0], w2.shape[1], dev, bwd)
         y = ops.gemm_fp8(a8, w2_8, mf.scale_inv(3), si2, fmt, fmt,
                          bias=None if b2 is None else b2.to(torch.bfloat16).contiguous())
-        sinv = mf.scale_inv_snapshot() if bwd else None
-        if sinv is not None:
-            sinv[1:2].copy_(si1)
-            sinv[4:5].copy_(si2)
+        snap = mf.scale_inv_snapshot() if bwd else None
+        sinv = (snap[0:1], si1, snap[3:4], si2) if bwd else None  # scale_inv of x, w1, act, w2 as of quantisation time
         ctx.saved_fp8 = (x8t, w1_8t, a8t, w2_8t, h if bwd else None, sinv)
         ctx.spec, ctx.x_shape, ctx.x_dtype = spec, x.shape, x.dtype
         ctx.dtypes = (w1.dtype, None if b1 is None else b1.dtype, w2.dtype, None if b2 is None else b2.dtype)
         ctx.need_dgrad, ctx.need_w = need_dgrad, need_w
+        if spec.with_skip:
+            ctx.set_materialize_grads(False)
+            return y.view(*x.shape[:-1], w2.shape[0]), x
         return y.view(*x.shape[:-1], w2.shape[0])
 
     @staticmethod
@@ -260,6 +280,9 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
         w2_8, w2s, w2t8, w2ts = _FP8SwiGLUMLPFn._mx_weights(spec, 1, w2, bwd)
         y = ops.gemm_mxfp8(a8, as_, w2_8, w2s, fmt, fmt, bias=None if b2 is None else b2.to(torch.bfloat16).contiguous())
         ctx.saved_fp8 = ((xt8, xts), (w1t8, w1ts), (at8, ats), (w2t8, w2ts), h if bwd else None, None)
+        if spec.with_skip:
+            ctx.set_materialize_grads(False)
+            return y.view(*x.shape[:-1], w2.shape[0]), x
         return y.view(*x.shape[:-1], w2.shape[0])
 
     @staticmethod
@@ -276,48 +299,54 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
         want_b1 = ctx.dtypes[1] is not None
         dh8, dhs, dht8, dhts, colsum = ops.mxfp8_dswiglu_quantize(h, dact, fmt_b, rowwise=ctx.need_dgrad, colwise=ctx.need_w,
                                                                   want_colsum=want_b1)
-        db1 = colsum.sum(0).to(ctx.dtypes[1]) if want_b1 else None
+        db1 = ops.colsum_finish(colsum, ctx.dtypes[1]) if want_b1 else None
         dx = ops.gemm_mxfp8(dh8, dhs, w1t8, w1ts, fmt_b, fmt_f) if ctx.need_dgrad else None
         dw1 = ops.gemm_mxfp8(dht8, dhts, xt8, xts, fmt_b, fmt_f) if ctx.need_w else None
         return dx, dw1, db1, dw2, db2
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         spec = ctx.spec
         if spec.recipe.mxfp8():
             dx, dw1, db1, dw2, db2 = _FP8SwiGLUMLPFn._backward_mx(ctx, dy)
-            return _FP8SwiGLUMLPFn._finish_backward(ctx, dx, dw1, db1, dw2, db2)
+            return _FP8SwiGLUMLPFn._finish_backward(ctx, dx, dw1, db1, dw2, db2, dskip)
         mb, fmt_f, fmt_b = spec.meta_bwd, spec.fmt_fwd, spec.fmt_bwd
         x8t, w1_8t, a8t, w2_8t, h, sinv = ctx.saved_fp8
         ctx.saved_fp8 = None
         g2 = _as_bf16_2d(dy)
         # fc2 backward (GEMM index 1: bwd slot 2)
-        g8, g8t = ops.cast_amax(g2, mb.scale(2), mb.amax(2), fmt_b, want_t=ctx.need_w)
-        dact = ops.gemm_fp8(g8, w2_8t, mb.scale_inv(2), sinv[4:5], fmt_b, fmt_f)
-        dw2 = ops.gemm_fp8(g8t, a8t, mb.scale_inv(2), sinv[3:4], fmt_b, fmt_f) if ctx.need_w else None
-        db2 = g2.sum(0, dtype=torch.float32).to(ctx.dtypes[3]) if ctx.dtypes[3] is not None else None
+        if ctx.dtypes[3] is not None:  # fc2 bias gradient rides on the cast of dy
+            g8, g8t, cs2 = ops.cast_amax(g2, mb.scale(2), mb.amax(2), fmt_b, want_t=ctx.need_w, want_colsum=True)
+            db2 = ops.colsum_finish(cs2, ctx.dtypes[3])
+        else:
+            g8, g8t = ops.cast_amax(g2, mb.scale(2), mb.amax(2), fmt_b, want_t=ctx.need_w)
+            db2 = None
+        dact = ops.gemm_fp8(g8, w2_8t, mb.scale_inv(2), sinv[3], fmt_b, fmt_f)
+        dw2 = ops.gemm_fp8(g8t, a8t, mb.scale_inv(2), sinv[2], fmt_b, fmt_f) if ctx.need_w else None
         # dSwiGLU + cast of fc1's grad_output (GEMM index 0: bwd slot 0) + fc1 bias gradient
         want_b1 = ctx.dtypes[1] is not None
         dh8, dh8t, colsum = ops.dswiglu_cast(h, dact, mb.scale(0), mb.amax(0), fmt_b, want_y=ctx.need_dgrad,
                                              want_t=ctx.need_w, want_colsum=want_b1)
-        db1 = colsum.sum(0).to(ctx.dtypes[1]) if want_b1 else None
-        dx = ops.gemm_fp8(dh8, w1_8t, mb.scale_inv(0), sinv[1:2], fmt_b, fmt_f) if ctx.need_dgrad else None
-        dw1 = ops.gemm_fp8(dh8t, x8t, mb.scale_inv(0), sinv[0:1], fmt_b, fmt_f) if ctx.need_w else None
-        return _FP8SwiGLUMLPFn._finish_backward(ctx, dx, dw1, db1, dw2, db2)
+        db1 = ops.colsum_finish(colsum, ctx.dtypes[1]) if want_b1 else None
+        dx = ops.gemm_fp8(dh8, w1_8t, mb.scale_inv(0), sinv[1], fmt_b, fmt_f) if ctx.need_dgrad else None
+        dw1 = ops.gemm_fp8(dh8t, x8t, mb.scale_inv(0), sinv[0], fmt_b, fmt_f) if ctx.need_w else None
+        return _FP8SwiGLUMLPFn._finish_backward(ctx, dx, dw1, db1, dw2, db2, dskip)
 
     @staticmethod
-    def _finish_backward(ctx, dx, dw1, db1, dw2, db2):
+    def _finish_backward(ctx, dx, dw1, db1, dw2, db2, dskip=None):
         spec = ctx.spec
         dln = None
         if ctx.norm is not None and dx is not None:
             xin, rstd, gam, ln_dtype = ctx.norm
             ctx.norm = None
-            dx, dgam = ops.rmsnorm_bwd(dx, xin, rstd, gam)
-            dln = dgam.to(ln_dtype)
+            dx, dln = ops.rmsnorm_bwd(dx, xin, rstd, gam, dres=_skip_2d(dskip, dx), dgamma_dtype=ln_dtype)
+            dskip = None
         if spec.trigger_bwd_update:
             FP8GlobalStateManager.reduce_and_update_fp8_tensors(forward=False)
         if dx is not None:
             dx = dx.view(ctx.x_shape).to(ctx.x_dtype)
+        if dskip is not None:
+            dx = dskip if dx is None else dx + dskip
         if dw1 is not None and dw1.dtype != ctx.dtypes[0]:
             dw1 = dw1.to(ctx.dtypes[0])
         if dw2 is not None and dw2.dtype != ctx.dtypes[2]:
@@ -504,13 +533,15 @@ class LayerNormLinear(_FP8Module):
             return _rmsnorm(x, self.layer_norm_weight, self.eps, self.zero_centered_gamma)
         return _layernorm(x, self.layer_norm_weight, self.layer_norm_bias, self.eps, self.zero_centered_gamma)
 
-    def forward(self, inp: torch.Tensor, is_first_microbatch=None):
+    def forward(self, inp: torch.Tensor, is_first_microbatch=None, _with_skip: bool = False):
+        """`_with_skip` (extension used by MultiheadAttention / the decoder layer): returns (out, skip) where `skip` carries
+        `inp` for the residual add, its gradient fused into the RMSNorm backward when the fused-norm path is active."""
         st = self._prepare(inp.device)
         ws, b = self._weights(), self._bias()
         if st is not None and _can_fuse_norm(self, st[0], inp) and not self.return_layernorm_output:
             recipe, mf, mb, first = st
             return _FP8LinearFn.apply(inp, b, _GemmSpec(recipe, mf, mb, 0, first, self.training, self.eps, self._wcache,
-                                                        is_first_microbatch), self.layer_norm_weight, *ws)
+                                                        is_first_microbatch, with_skip=_with_skip), self.layer_norm_weight, *ws)
         ln = self._norm(inp)
         if st is None:
             w = ws[0] if len(ws) == 1 else torch.cat(ws, 0)
@@ -519,6 +550,8 @@ class LayerNormLinear(_FP8Module):
             recipe, mf, mb, first = st
             out = _FP8LinearFn.apply(ln, b, _GemmSpec(recipe, mf, mb, 0, first, self.training, wcache=self._wcache,
                                                       first_mb=is_first_microbatch), None, *ws)
+        if _with_skip:  # unfused route: the residual is the input itself (autograd adds its gradient)
+            return out, inp
         return (out, ln) if self.return_layernorm_output else out
 
 
@@ -573,13 +606,17 @@ class LayerNormMLP(_FP8Module):
             return _rmsnorm(x, self.layer_norm_weight, self.eps, self.zero_centered_gamma)
         return _layernorm(x, self.layer_norm_weight, self.layer_norm_bias, self.eps, self.zero_centered_gamma)
 
-    def forward(self, inp: torch.Tensor, is_first_microbatch=None) -> torch.Tensor:
+    def forward(self, inp: torch.Tensor, is_first_microbatch=None, _with_skip: bool = False):
         st = self._prepare(inp.device)
         if (st is not None and self.activation == "swiglu" and self.fused_swiglu and _can_fuse_norm(self, st[0], inp)):
             recipe, mf, mb, first = st  # K9 + K10: norm -> cast, fc1, SwiGLU -> cast, fc2 in one autograd node
             return _FP8SwiGLUMLPFn.apply(inp, self.fc1_weight, self.fc1_bias, self.fc2_weight, self.fc2_bias,
                                          _GemmSpec(recipe, mf, mb, 0, first, self.training, self.eps, self._wcache,
-                                                   is_first_microbatch), self.layer_norm_weight)
+                                                   is_first_microbatch, with_skip=_with_skip), self.layer_norm_weight)
+        out = self._unfused(inp, st, is_first_microbatch)
+        return (out, inp) if _with_skip else out  # unfused route: the residual is the input itself
+
+    def _unfused(self, inp, st, is_first_microbatch):
         ln = self._norm(inp)
         if st is None:
             h = F.linear(ln, self.fc1_weight.to(ln.dtype), None if self.fc1_bias is None else self.fc1_bias.to(ln.dtype))

@@ -60,10 +60,22 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+def colsum_finish(partial: torch.Tensor, dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """[P, C] fp32 partial column sums -> [C] in `dtype` (bf16 / fp32): one launch instead of sum + cast."""
+    _dev(partial)
+    assert partial.dtype == torch.float32 and partial.dim() == 2 and partial.is_contiguous()
+    P, C = partial.shape
+    if dtype not in (torch.bfloat16, torch.float32):
+        return partial.sum(0).to(dtype)
+    out = torch.empty(C, dtype=dtype, device=partial.device)
+    _lib.check(_lib.load().mi_colsum_finish(partial.data_ptr(), P, C, out.data_ptr(), 0 if dtype == torch.bfloat16 else 1, _stream()),
+               "mi_colsum_finish")
+    return out
+
+
 def cast_amax(x: torch.Tensor, scale: torch.Tensor, amax: Optional[torch.Tensor], fmt: int,
               want_y: bool = True, want_t: bool = True,
-              y: Optional[torch.Tensor] = None, yT: Optional[torch.Tensor] = None
-              ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+              y: Optional[torch.Tensor] = None, yT: Optional[torch.Tensor] = None, want_colsum: bool = False):
     """K1/K2.  x bf16 [R, C] contiguous -> (y u8 [R, C], yT u8 [C, R]); amax (1-elem f32 view) is
     atomically maxed with max|x|.  `y` / `yT` may be preallocated row-slices of larger buffers
     (their stride(0) is used as leading dimension)."""
@@ -79,17 +91,20 @@ def cast_amax(x: torch.Tensor, scale: torch.Tensor, amax: Optional[torch.Tensor]
         assert y.dtype == torch.uint8 and y.shape == (R, C) and y.stride(1) == 1
     if yT is not None:
         assert yT.dtype == torch.uint8 and yT.shape == (C, R) and yT.stride(1) == 1
-    args = (x.data_ptr(), _ptr(y), _ptr(yT), scale.data_ptr(), _ptr(amax), R, C,
-            y.stride(0) if y is not None else C, yT.stride(0) if yT is not None else R, fmt, _stream())
+    cs = torch.empty(((R + 127) // 128, C), dtype=torch.float32, device=x.device) if want_colsum else None
+    tail = (R, C, y.stride(0) if y is not None else C, yT.stride(0) if yT is not None else R, fmt, _stream())
+    head = (x.data_ptr(), _ptr(y), _ptr(yT), scale.data_ptr(), _ptr(amax))
+    fn = _lib.load().mi_cast_amax_colsum if want_colsum else _lib.load().mi_cast_amax
+    args = head + ((cs.data_ptr(),) if want_colsum else ()) + tail
     t = KernelTimer.active
     if t is None:
-        rc = _lib.load().mi_cast_amax(*args)
+        rc = fn(*args)
     else:
         nb = R * C * (2 + (y is not None) + (yT is not None))
         with t.span("cast_amax", f"{R}x{C}", float(R * C), float(nb)):
-            rc = _lib.load().mi_cast_amax(*args)
+            rc = fn(*args)
     _lib.check(rc, "mi_cast_amax")
-    return y, yT
+    return (y, yT, cs) if want_colsum else (y, yT)
 
 
 def scale_update(amax_history: torch.Tensor, scale: torch.Tensor, scale_inv: torch.Tensor,
@@ -290,8 +305,9 @@ def norm_cast(x: torch.Tensor, rstd: torch.Tensor, gamma: torch.Tensor, scale: t
 
 
 def rmsnorm_bwd(dy: torch.Tensor, x: torch.Tensor, rstd: torch.Tensor, gamma: torch.Tensor,
-                dres: Optional[torch.Tensor] = None, n_partials: int = 512):
-    """K9 backward: (dx bf16 [R, C], dgamma fp32 [C]).  dgamma is the fixed-order sum of per-block partials."""
+                dres: Optional[torch.Tensor] = None, n_partials: int = 512, dgamma_dtype: torch.dtype = torch.float32):
+    """K9 backward: (dx bf16 [R, C], dgamma [C] in `dgamma_dtype`).  dgamma is the fixed-order sum of per-block partials;
+    `dres` (bf16 [R, C]) is added to dx (the gradient arriving over the residual connection)."""
     _dev(dy, x, rstd, gamma, dres)
     assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous()
     R, C = x.shape
@@ -301,7 +317,7 @@ def rmsnorm_bwd(dy: torch.Tensor, x: torch.Tensor, rstd: torch.Tensor, gamma: to
     rc = _lib.load().mi_rmsnorm_bwd(dy.data_ptr(), x.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), _ptr(dres), dx.data_ptr(),
                                     part.data_ptr(), n_partials, R, C, _stream())
     _lib.check(rc, "mi_rmsnorm_bwd")
-    return dx, part.sum(0)
+    return dx, colsum_finish(part, dgamma_dtype)
 
 
 def _mx_alloc(R: int, C: int, dev, rowwise: bool, colwise: bool):

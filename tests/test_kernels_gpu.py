@@ -566,3 +566,21 @@ def test_gemm_mxfp8_streamk_vs_oracle(ops, dev):
     tT = lambda v: torch.from_numpy(np.ascontiguousarray(v.T)).to(dev)
     d = ops.gemm_mxfp8(t(a8), tT(ae), t(b8), tT(be), algo=44)
     assert_gemm_close(d.float().cpu().numpy(), ref, "mx stream-K")
+
+
+@pytest.mark.parametrize("shape", [(8, 16), (200, 136), (1024, 3072)])
+def test_cast_colsum_and_finish(ops, dev, shape):
+    """mi_cast_amax_colsum: same bytes / amax as mi_cast_amax plus fp32 column sums (the bias gradient)."""
+    R, C = shape
+    x = (torch.randn(R, C, generator=torch.Generator().manual_seed(R)) * 3).to(torch.bfloat16)
+    sc = _f32(0.37, dev)
+    a0, a1 = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    y0, t0 = ops.cast_amax(x.to(dev), sc, a0, O.E5M2)
+    y1, t1, part = ops.cast_amax(x.to(dev), sc, a1, O.E5M2, want_colsum=True)
+    assert torch.equal(y0, y1) and torch.equal(t0, t1) and torch.equal(a0, a1)
+    assert part.shape == ((R + 127) // 128, C)
+    ref = O.bf16_bits_to_f32(bf16_bits(x)).astype(np.float64).sum(0)
+    got32 = ops.colsum_finish(part, torch.float32).cpu().numpy()
+    np.testing.assert_allclose(got32, ref, rtol=1e-5, atol=1e-4 * np.sqrt(R))
+    got16 = ops.colsum_finish(part, torch.bfloat16).float().cpu().numpy()
+    np.testing.assert_array_equal(got16, O.bf16_bits_to_f32(O.f32_to_bf16_bits(got32)))

@@ -486,3 +486,43 @@ def test_dot_product_attention_flash_path_matches_sdpa(te, dev):
     for a, b, name in zip(got, (o2.detach(), q.grad, k.grad, v.grad), ("o", "dq", "dk", "dv")):
         rel = ((a.float() - b.float()).norm() / b.float().norm()).item()
         assert rel < 1e-2, f"{name}: {rel:.4g}"
+
+
+@pytest.mark.parametrize("scenario", ["default", "mxfp8"])
+def test_decoder_layer_skip_fusion_matches_plain_residual(te, dev, scenario):
+    """The `_with_skip` route (residual gradient added inside the RMSNorm-backward kernel) against plain `h + f(h)`."""
+    from llm_fp8_amd import llama
+    cfg = llama.llama_config("llama-3.2-1b", num_hidden_layers=1, hidden_size=512, intermediate_size=1024, num_attention_heads=4,
+                             num_key_value_heads=2, head_dim=128, vocab_size=1024, max_position_embeddings=256)
+    torch.manual_seed(5)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device(dev):
+            layer = llama.decoder_layer_cls(scenario)(cfg, 0)
+    finally:
+        torch.set_default_dtype(prev)
+    layer.to(dev).train()
+    x = torch.randn(2, 128, cfg.hidden_size, device=dev, dtype=torch.bfloat16)
+
+    def plain(h):
+        with te.fp8_autocast(enabled=True, fp8_recipe=layer.attn_recipe):
+            h = h + layer.self_attention(h, rotary_pos_emb=layer.te_rope_emb)
+        with te.fp8_autocast(enabled=True, fp8_recipe=layer.mlp_recipe):
+            return h + layer.layernorm_mlp(h)
+
+    for _ in range(3):  # settle the delayed-scaling state: same input every time, so both routes then see the same scales
+        xi = x.clone().requires_grad_(True)
+        layer(xi).float().square().mean().backward()
+        layer.zero_grad()
+    outs = []
+    for fn in (layer, plain):
+        xi = x.clone().requires_grad_(True)
+        y = fn(xi)
+        y.float().square().mean().backward()
+        outs.append((y.detach(), xi.grad.clone(), layer.self_attention.layernorm_qkv.layer_norm_weight.grad.clone(),
+                     layer.layernorm_mlp.fc1_weight.grad.clone()))
+        layer.zero_grad()
+    for a, b, name in zip(outs[0], outs[1], ("y", "dx", "dgamma", "dw1")):
+        rel = ((a.float() - b.float()).norm() / b.float().norm()).item()
+        assert rel < (3e-2 if name == "dgamma" else 1e-2), f"{name}: {rel:.4g}"  # only the rounding of dx + dskip moves (and what it re-quantises to upstream)
