@@ -66,7 +66,7 @@ int mi_cast_amax(const void* x_bf16, void* y_fp8, void* yT_fp8, const float* sca
                  int64_t rows, int64_t cols, int64_t ld_y, int64_t ld_yT, int fmt, void* stream);
 /*
  * mi_cast_amax that also returns the column sums of x (the bias gradient when x = grad_output of a Linear,
- * `db = sum_M dy`): colsum_partial [ceil(rows/128), cols] fp32, one row per 128-row tile, to be reduced by
+ * `db = sum_M dy`): colsum_partial [ceil(rows/64), cols] fp32, one row per 64-row tile, to be reduced by
  * mi_colsum_finish.  Fixed summation order: reproducible.
  */
 int mi_cast_amax_colsum(const void* x_bf16, void* y_fp8, void* yT_fp8, const float* scale, float* amax,

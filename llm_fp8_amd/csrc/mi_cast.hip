@@ -15,28 +15,50 @@
 
 namespace mi {
 
-// COLSUM: also emits colsum[tile_r, c] = sum of the tile's (up to) 128 rows of x[:, c] in fp32 -- the bias gradient of a
+// COLSUM: also emits colsum[tile_r, c] = sum of the tile's (up to) 64 rows of x[:, c] in fp32 -- the bias gradient of a
 // Linear comes out of the cast of its grad_output instead of a separate reduction pass over dy.
+//
+// Persistent form: every WAVE walks 64x64-element tiles (one 8x8 block per lane) with stride = waves in the grid, the 8
+// row loads of its next tile already in flight while the current tile is converted and stored.  A one-shot grid (one tile
+// per workgroup, all workgroups resident at once) runs in two global phases -- everybody loads, then everybody stores --
+// and measured the same 25 us for 8192x3072 with or without the transposed copy; the loop overlaps the two directions.
+// The 4 waves of a workgroup take 4 neighbouring column tiles, so a workgroup row-load covers 512 contiguous bytes.
 template <int FMT, bool WRITE_Y, bool WRITE_T, bool COLSUM = false>
 __global__ __launch_bounds__(256) void cast_amax_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ y,
                                                         uint8_t* __restrict__ yT, const float* __restrict__ scale_p,
                                                         float* amax_out, int rows, int cols, int64_t ld_y,
                                                         int64_t ld_yT, int tiles_c, float* __restrict__ colsum = nullptr) {
   __shared__ float s_amax[4];
-  __shared__ float s_cs[COLSUM ? 4 * 64 : 1];
-  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile_r = blockIdx.x / tiles_c, tile_c = blockIdx.x % tiles_c;
-  const int r0 = tile_r * 128 + (wave >> 1) * 64 + (lane >> 3) * 8;
-  const int c0 = tile_c * 128 + (wave & 1) * 64 + (lane & 7) * 8;
+  const int ntiles = ((rows + 63) / 64) * tiles_c;
+  const int stride = gridDim.x * 4;
+  const int lr = (lane >> 3) * 8, lc = (lane & 7) * 8;
   const float scale = *scale_p;
   float amax = 0.0f;
-  const bool active = (r0 < rows) && (c0 < cols);  // dims are multiples of 8: blocks are all-in or all-out
-  if (active) {
-    v4i raw[8];
-    const uint16_t* src = x + (int64_t)r0 * cols + c0;
+  int t = blockIdx.x * 4 + wave;
+  v4i nxt[8];
+  auto load_tile = [&](int tt, v4i (&raw)[8]) {
+    const int r0 = (tt / tiles_c) * 64 + lr, c0 = (tt % tiles_c) * 64 + lc;
+    if (r0 < rows && c0 < cols) {  // dims are multiples of 8: blocks are all-in or all-out
+      const uint16_t* src = x + (int64_t)r0 * cols + c0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) raw[i] = *reinterpret_cast<const v4i*>(src + (int64_t)i * cols);
+      for (int i = 0; i < 8; ++i) raw[i] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(src + (int64_t)i * cols));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) raw[i] = (v4i){0, 0, 0, 0};
+    }
+  };
+  if (t < ntiles) load_tile(t, nxt);
+  while (t < ntiles) {
+    v4i raw[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) raw[i] = nxt[i];
+    const int tn = t + stride;
+    if (tn < ntiles) load_tile(tn, nxt);
+    const int tile_r = t / tiles_c;
+    const int r0 = tile_r * 64 + lr, c0 = (t % tiles_c) * 64 + lc;
+    const bool active = (r0 < rows) && (c0 < cols);
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     u32 screen = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -67,41 +89,40 @@ __global__ __launch_bounds__(256) void cast_amax_kernel(const uint16_t* __restri
       lo[i] = cvt4_fp8<FMT>(f[0] * scale, f[1] * scale, f[2] * scale, f[3] * scale);
       hi[i] = cvt4_fp8<FMT>(f[4] * scale, f[5] * scale, f[6] * scale, f[7] * scale);
     }
-    if (WRITE_Y) {
-      uint8_t* dst = y + (int64_t)r0 * ld_y + c0;
+    if (active) {
+      if (WRITE_Y) {
+        uint8_t* dst = y + (int64_t)r0 * ld_y + c0;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) *reinterpret_cast<uint2*>(dst + (int64_t)i * ld_y) = make_uint2(lo[i], hi[i]);
-    }
-    if (WRITE_T) {
-      u32 a[4], b[4], c[4], d[4];
-      transpose4x4(lo[0], lo[1], lo[2], lo[3], a[0], a[1], a[2], a[3]);  // cols 0..3, rows 0..3
-      transpose4x4(lo[4], lo[5], lo[6], lo[7], b[0], b[1], b[2], b[3]);  // cols 0..3, rows 4..7
-      transpose4x4(hi[0], hi[1], hi[2], hi[3], c[0], c[1], c[2], c[3]);  // cols 4..7, rows 0..3
-      transpose4x4(hi[4], hi[5], hi[6], hi[7], d[0], d[1], d[2], d[3]);  // cols 4..7, rows 4..7
-      uint8_t* dst = yT + (int64_t)c0 * ld_yT + r0;
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<uint2*>(dst + (int64_t)i * ld_y) = make_uint2(lo[i], hi[i]);
+      }
+      if (WRITE_T) {
+        u32 a[4], b[4], c[4], d[4];
+        transpose4x4(lo[0], lo[1], lo[2], lo[3], a[0], a[1], a[2], a[3]);  // cols 0..3, rows 0..3
+        transpose4x4(lo[4], lo[5], lo[6], lo[7], b[0], b[1], b[2], b[3]);  // cols 0..3, rows 4..7
+        transpose4x4(hi[0], hi[1], hi[2], hi[3], c[0], c[1], c[2], c[3]);  // cols 4..7, rows 0..3
+        transpose4x4(hi[4], hi[5], hi[6], hi[7], d[0], d[1], d[2], d[3]);  // cols 4..7, rows 4..7
+        uint8_t* dst = yT + (int64_t)c0 * ld_yT + r0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        *reinterpret_cast<uint2*>(dst + (int64_t)j * ld_yT) = make_uint2(a[j], b[j]);
-        *reinterpret_cast<uint2*>(dst + (int64_t)(j + 4) * ld_yT) = make_uint2(c[j], d[j]);
+        for (int j = 0; j < 4; ++j) {
+          *reinterpret_cast<uint2*>(dst + (int64_t)j * ld_yT) = make_uint2(a[j], b[j]);
+          *reinterpret_cast<uint2*>(dst + (int64_t)(j + 4) * ld_yT) = make_uint2(c[j], d[j]);
+        }
       }
     }
-  }
-  if (COLSUM) {
+    if (COLSUM) {  // inactive lanes carry zeros; lanes 0..7 end up with the 64-row sums of their 8 columns
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      cs[j] += __shfl_xor(cs[j], 8);
-      cs[j] += __shfl_xor(cs[j], 16);
-      cs[j] += __shfl_xor(cs[j], 32);
+      for (int j = 0; j < 8; ++j) {
+        cs[j] += __shfl_xor(cs[j], 8);
+        cs[j] += __shfl_xor(cs[j], 16);
+        cs[j] += __shfl_xor(cs[j], 32);
+      }
+      if (lane < 8 && c0 < cols) {
+        float* dst = colsum + (int64_t)tile_r * cols + c0;
+        *reinterpret_cast<v4f*>(dst) = (v4f){cs[0], cs[1], cs[2], cs[3]};
+        *reinterpret_cast<v4f*>(dst + 4) = (v4f){cs[4], cs[5], cs[6], cs[7]};
+      }
     }
-    if (lane < 8) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s_cs[wave * 64 + lane * 8 + j] = cs[j];
-    }
-    __syncthreads();
-    if (tid < 128) {
-      const int c = tile_c * 128 + tid;
-      if (c < cols) colsum[(int64_t)tile_r * cols + c] = s_cs[(tid >> 6) * 64 + (tid & 63)] + s_cs[(2 + (tid >> 6)) * 64 + (tid & 63)];
-    }
+    t = tn;
   }
   if (amax_out != nullptr) {
     amax = wave_max(amax);
@@ -112,6 +133,16 @@ __global__ __launch_bounds__(256) void cast_amax_kernel(const uint16_t* __restri
       if (m > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(amax_out), __float_as_uint(m));
     }
   }
+}
+
+static int cast_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
 }
 
 // second stage of every [P, C] fp32 partial column sum (cast, dSwiGLU, RMSNorm backward): out[c] = sum_p part[p, c]
@@ -146,8 +177,10 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
 template <int FMT>
 static int launch_cast(const void* x, void* y, void* yT, const float* scale, float* amax, int64_t rows,
                        int64_t cols, int64_t ld_y, int64_t ld_yT, hipStream_t st, float* colsum = nullptr) {
-  const int tiles_r = (int)((rows + 127) / 128), tiles_c = (int)((cols + 127) / 128);
-  dim3 grid((unsigned)(tiles_r * tiles_c)), block(256);
+  const int tiles_r = (int)((rows + 63) / 64), tiles_c = (int)((cols + 63) / 64);
+  const int64_t wgs = ((int64_t)tiles_r * tiles_c + 3) / 4;
+  const int64_t cap = (int64_t)cast_num_cus() * 3;  // what stays resident (3-4 waves per SIMD): 2-8 tiles per wave on the step's sizes
+  dim3 grid((unsigned)(wgs < cap ? wgs : cap)), block(256);
   const uint16_t* xp = (const uint16_t*)x;
   uint8_t *yp = (uint8_t*)y, *tp = (uint8_t*)yT;
   if (colsum) {
@@ -185,7 +218,7 @@ static int cast_amax_impl(const void* x_bf16, void* y_fp8, void* yT_fp8, const f
   MI_CHECK_ARG(rows >= 0 && cols >= 0, "mi_cast_amax: negative shape");
   MI_CHECK_ARG(rows % 8 == 0 && cols % 8 == 0, "mi_cast_amax: rows (%lld) and cols (%lld) must be multiples of 8",
                (long long)rows, (long long)cols);
-  MI_CHECK_ARG(rows < (1LL << 31) && cols < (1LL << 31) && ((rows + 127) / 128) * ((cols + 127) / 128) < (1LL << 31),
+  MI_CHECK_ARG(rows < (1LL << 31) && cols < (1LL << 31) && ((rows + 63) / 64) * ((cols + 63) / 64) < (1LL << 31),
                "mi_cast_amax: shape too large");
   MI_CHECK_ARG(!y_fp8 || (ld_y >= cols && ld_y % 8 == 0), "mi_cast_amax: ld_y must be >= cols and a multiple of 8");
   MI_CHECK_ARG(!yT_fp8 || (ld_yT >= rows && ld_yT % 8 == 0), "mi_cast_amax: ld_yT must be >= rows and a multiple of 8");

@@ -91,7 +91,7 @@ def cast_amax(x: torch.Tensor, scale: torch.Tensor, amax: Optional[torch.Tensor]
         assert y.dtype == torch.uint8 and y.shape == (R, C) and y.stride(1) == 1
     if yT is not None:
         assert yT.dtype == torch.uint8 and yT.shape == (C, R) and yT.stride(1) == 1
-    cs = torch.empty(((R + 127) // 128, C), dtype=torch.float32, device=x.device) if want_colsum else None
+    cs = torch.empty(((R + 63) // 64, C), dtype=torch.float32, device=x.device) if want_colsum else None
     tail = (R, C, y.stride(0) if y is not None else C, yT.stride(0) if yT is not None else R, fmt, _stream())
     head = (x.data_ptr(), _ptr(y), _ptr(yT), scale.data_ptr(), _ptr(amax))
     fn = _lib.load().mi_cast_amax_colsum if want_colsum else _lib.load().mi_cast_amax

@@ -578,7 +578,7 @@ def test_cast_colsum_and_finish(ops, dev, shape):
     y0, t0 = ops.cast_amax(x.to(dev), sc, a0, O.E5M2)
     y1, t1, part = ops.cast_amax(x.to(dev), sc, a1, O.E5M2, want_colsum=True)
     assert torch.equal(y0, y1) and torch.equal(t0, t1) and torch.equal(a0, a1)
-    assert part.shape == ((R + 127) // 128, C)
+    assert part.shape == ((R + 63) // 64, C)
     ref = O.bf16_bits_to_f32(bf16_bits(x)).astype(np.float64).sum(0)
     got32 = ops.colsum_finish(part, torch.float32).cpu().numpy()
     np.testing.assert_allclose(got32, ref, rtol=1e-5, atol=1e-4 * np.sqrt(R))

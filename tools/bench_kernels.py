@@ -139,6 +139,11 @@ def main():
             print(f"cast+T {R}x{C}: {t*1e6:8.1f} us {4.0*R*C/t/1e9:8.1f} GB/s (alg 4 B/elem)", flush=True)
             t = time_fn(lambda: ops.cast_amax(x, one, amax, 0, y=y, want_t=False), args.iters)
             print(f"cast   {R}x{C}: {t*1e6:8.1f} us {3.0*R*C/t/1e9:8.1f} GB/s (alg 3 B/elem)", flush=True)
+            t = time_fn(lambda: ops.cast_amax(x, one, amax, 0, yT=yT, want_y=False), args.iters)
+            print(f"castT  {R}x{C}: {t*1e6:8.1f} us {3.0*R*C/t/1e9:8.1f} GB/s (alg 3 B/elem, transposed copy only)", flush=True)
+            x2 = torch.empty_like(x)
+            t = time_fn(lambda: x2.copy_(x), args.iters)
+            print(f"copy   {R}x{C}: {t*1e6:8.1f} us {4.0*R*C/t/1e9:8.1f} GB/s (torch bf16 copy, 4 B/elem)", flush=True)
     if "mx" in args.which:
         for (R, C) in ((8192, 3072), (8192, 16384)):
             x = torch.randn((R, C), device=dev, dtype=torch.float32, generator=g).to(torch.bfloat16)
