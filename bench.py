@@ -68,9 +68,10 @@ def cpu_baseline(model_name: str, seq: int = 128, layers=(2, 4), timed_steps: in
 def pmc_traffic(by_tag):
     """Per-launch fabric bytes of the GEMM kernel from the committed rocprofv3 PMC passes (profiles/), averaged over the
     launch mix of this run; shapes without a PMC row (lm_head) are left out of the average."""
-    path = os.path.join(ROOT, "profiles", "r01_gemm_pmc_traffic.json")
-    if not os.path.exists(path):
+    cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_gemm_pmc_traffic.json"))
+    if not cands:
         return None, "no PMC file"
+    path = os.path.join(ROOT, "profiles", cands[-1])  # newest round
     tab = json.load(open(path))["sites"]
     num = den = 0.0
     for tag, v in by_tag.items():
@@ -80,7 +81,7 @@ def pmc_traffic(by_tag):
     if den == 0:
         return None, "no measured shape in this run"
     return num / den, ("avg bytes per launch over the decoder GEMM sites, rocprofv3 --pmc FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, "
-                       "separate passes (profiles/r01_gemm_pmc_traffic.json); counts Infinity-Cache hits, i.e. L2-miss traffic")
+                       f"separate passes (profiles/{cands[-1]}); counts Infinity-Cache hits, i.e. L2-miss traffic")
 
 
 def main():
