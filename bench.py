@@ -6,8 +6,9 @@ decoder Linear and lm_head running the hand-written HIP FP8 path (cast+amax, sca
 
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
-Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events around every FP8 GEMM launch
-of the timed steps; `cpu_baseline` is the repo's own no-TE HF bf16 path timed on this host's CPU cores
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events around every FP8 GEMM launch of every
+second timed step (an event costs ~4.5 us of queue time: bracketing every kernel of every step slowed the step by 5 %,
+the GEMMs of every step by 3 %); `cpu_baseline` is the repo's own no-TE HF bf16 path timed on this host's CPU cores
 (rank 0, N = 1 only).
 """
 from __future__ import annotations
@@ -127,17 +128,26 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    aux_timer = KernelTimer(kinds=("cast_amax", "mxfp8_quantize", "attn_fwd", "attn_bwd"))  # informational, outside the timed region
     for i in range(args.warmup):
-        train.train_step(model, batches[i % 4], opt, sched, cfg)
-    timer = KernelTimer()
+        if i == args.warmup - 1 and not args.no_kernel_timing:
+            with aux_timer.install():
+                train.train_step(model, batches[i % 4], opt, sched, cfg)
+        else:
+            train.train_step(model, batches[i % 4], opt, sched, cfg)
+    # inside the timed region only the FP8 GEMM launches are bracketed by HIP events (every event costs queue time)
+    timer = KernelTimer(kinds=("gemm_fp8", "gemm_mxfp8"))
     sync()
     t0 = time.perf_counter()
     if args.no_kernel_timing:
         for i in range(args.steps):
             loss = train.train_step(model, batches[i % 4], opt, sched, cfg)
     else:
-        with timer.install():
-            for i in range(args.steps):
+        for i in range(args.steps):
+            if i % 2 == 0:  # GEMM launches of every other timed step carry HIP events (each event costs ~4.5 us of queue time)
+                with timer.install():
+                    loss = train.train_step(model, batches[i % 4], opt, sched, cfg)
+            else:
                 loss = train.train_step(model, batches[i % 4], opt, sched, cfg)
     sync()
     elapsed = time.perf_counter() - t0
@@ -174,18 +184,25 @@ def main():
                                    "kernel": kind, "launches": g["launches"],
                                    "avg_launch_us": g["seconds"] / g["launches"] * 1e6,
                                    "avg_flop_per_launch": g["work"] / g["launches"],
-                                   "gemm_ms_per_step": g["seconds"] / args.steps * 1e3}
+                                   "gemm_ms_per_step": g["seconds"] / ((args.steps + 1) // 2) * 1e3,
+                                   "bracketed_steps": f"every 2nd of the {args.steps} timed steps ({(args.steps + 1) // 2} steps, {g['launches']} launches)"}
                 sites = {}
                 for tag, v in sorted(g["by_tag"].items(), key=lambda kv: -kv[1]["seconds"]):
                     sites[tag] = {"tflops": v["work"] / v["seconds"] / 1e12, "us": v["seconds"] / v["launches"] * 1e6,
-                                  "launches_per_step": v["launches"] / args.steps}
+                                  "launches_per_step": v["launches"] / ((args.steps + 1) // 2)}
                 out["gemm_sites"] = sites
             hbm = {}
+            aux = aux_timer.summarize()  # one warm-up step, not part of the timed region
             for k in ("cast_amax", "mxfp8_quantize"):
-                if k in summ and summ[k]["seconds"] > 0:
-                    hbm[k] = {"GB/s": summ[k]["bytes"] / summ[k]["seconds"] / 1e9, "ms_per_step": summ[k]["seconds"] / args.steps * 1e3,
-                              "launches_per_step": summ[k]["launches"] / args.steps}
+                if k in aux and aux[k]["seconds"] > 0:
+                    hbm[k] = {"GB/s": aux[k]["bytes"] / aux[k]["seconds"] / 1e9, "ms_per_step": aux[k]["seconds"] * 1e3,
+                              "launches_per_step": aux[k]["launches"]}
+            for k in ("attn_fwd", "attn_bwd"):
+                if k in aux and aux[k]["seconds"] > 0:
+                    hbm[k] = {"TFLOP/s": aux[k]["work"] / aux[k]["seconds"] / 1e12, "ms_per_step": aux[k]["seconds"] * 1e3,
+                              "launches_per_step": aux[k]["launches"]}
             out["hbm_kernels"] = hbm
+            out["hbm_kernels_note"] = "cast / quantise / attention kernels bracketed during the last warm-up step only"
         if world == 1 and not args.no_cpu_baseline:
             del model, opt
             torch.cuda.empty_cache()
