@@ -144,6 +144,15 @@ def main():
             x2 = torch.empty_like(x)
             t = time_fn(lambda: x2.copy_(x), args.iters)
             print(f"copy   {R}x{C}: {t*1e6:8.1f} us {4.0*R*C/t/1e9:8.1f} GB/s (torch bf16 copy, 4 B/elem)", flush=True)
+    if "swiglu" in args.which:
+        R, F = 8192, 8192
+        h = torch.randn((R, 2 * F), device=dev, dtype=torch.float32, generator=g).to(torch.bfloat16)
+        d = torch.randn((R, F), device=dev, dtype=torch.float32, generator=g).to(torch.bfloat16)
+        amax = torch.zeros(1, device=dev)
+        t = time_fn(lambda: ops.swiglu_cast(h, one, amax, 0), args.iters)
+        print(f"swiglu  fwd {R}x{F}: {t*1e6:8.1f} us {6.0*R*F/t/1e9:8.1f} GB/s (6 B/out-elem)", flush=True)
+        t = time_fn(lambda: ops.dswiglu_cast(h, d, one, amax, 0, want_colsum=True), args.iters)
+        print(f"dswiglu bwd {R}x{F}: {t*1e6:8.1f} us {10.0*R*F/t/1e9:8.1f} GB/s (10 B/gate-elem)", flush=True)
     if "mx" in args.which:
         for (R, C) in ((8192, 3072), (8192, 16384)):
             x = torch.randn((R, C), device=dev, dtype=torch.float32, generator=g).to(torch.bfloat16)
