@@ -97,7 +97,8 @@ int mi_scale_update(float* amax_history, float* scale, float* scale_inv, const f
  *       4 = persistent eight-phase (one workgroup per CU, epilogue overlapped with the next tile).
  * 2/3 need M,N % 256 == 0 and K % 128 == 0; 4 additionally K % 256 == 0, bf16 output and operands
  * below 2 GiB (M, N may also be multiples of 192: workgroup tiles of 256/192 rows x 256/192 columns are picked per shape).
- * auto picks 4, else 3, else 1.  40-43 force one tile shape of 4, 44 = stream-K form of 4 (see mi_gemm_set_workspace),
+ * auto picks 4, else 3, else 1.  5 = the kernel of 4 launched with one workgroup per tile (hardware-balanced: for use while
+ * collectives hold part of the chip).  40-43 force one tile shape of 4, 44 = stream-K form of 4 (see mi_gemm_set_workspace),
  * 45 = 4; 13-17 are timing-only diagnostic builds.
  */
 int mi_gemm_fp8(const void* A, const void* B, void* D, const float* sa_inv, const float* sb_inv,

@@ -939,10 +939,12 @@ static int sk_units(int64_t M, int64_t N, int64_t K, bool force) {
 template <int FA, int FB, bool MX, bool BIAS, int ABL, int MA1, int NB1>
 static void launch_p8_cfg(const uint8_t* a, const uint8_t* b, uint16_t* D, const float* sa_inv, const float* sb_inv,
                           const uint8_t* SA, const uint8_t* SB, const uint16_t* bias, int64_t M, int64_t N, int64_t K,
-                          int64_t lda, int64_t ldb, int64_t ldd, hipStream_t st) {
+                          int64_t lda, int64_t ldb, int64_t ldd, hipStream_t st, bool one_tile_per_wg = false) {
   constexpr int TBM = 2 * (64 + 16 * MA1), TBN = 4 * (32 + 16 * NB1);
   const int tiles_m = (int)(M / TBM), tiles_n = (int)(N / TBN);
-  const int grid = tiles_m * tiles_n < num_cus() ? tiles_m * tiles_n : num_cus();
+  // one_tile_per_wg (algo 5): same kernel, one workgroup per tile, so the hardware dispatcher balances the tiles over whatever
+  // CUs are free -- the form to use while other kernels (RCCL collectives) hold part of the chip
+  const int grid = (one_tile_per_wg || tiles_m * tiles_n < num_cus()) ? tiles_m * tiles_n : num_cus();
   hipLaunchKernelGGL((gemm_256_p8<FA, FB, ABL, MX, BIAS, MA1, NB1, false>), dim3(grid), dim3(512), 0, st, a, b, D, sa_inv, sb_inv, (int)K,
                      (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb), (int)(M * ldd * 2), SA, SB,
                      (int)M, (int)N, bias, (float*)nullptr, (unsigned int*)nullptr, 0u, 0);
@@ -996,7 +998,7 @@ static int launch_p8(const uint8_t* a, const uint8_t* b, uint16_t* D, const floa
     return MI_ERR_SHAPE;
   }
 #define MI_P8(MXv, BIASv, ABLv, MA1v, NB1v) \
-  launch_p8_cfg<FA, FB, MXv, BIASv, ABLv, MA1v, NB1v>(a, b, D, sa_inv, sb_inv, SA, SB, bias, M, N, K, lda, ldb, ldd, st)
+  launch_p8_cfg<FA, FB, MXv, BIASv, ABLv, MA1v, NB1v>(a, b, D, sa_inv, sb_inv, SA, SB, bias, M, N, K, lda, ldb, ldd, st, algo == 5)
 #define MI_P8_CFG(MXv, BIASv, ABLv)                                 \
   switch (cfg) {                                                    \
     case 0: MI_P8(MXv, BIASv, ABLv, 4, 2); break;                   \
@@ -1035,7 +1037,7 @@ static int launch_fmt(const void* A, const void* B, void* D, const float* sa_inv
     int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
     hipLaunchKernelGGL((gemm_256_8ph<FA, FB, OUT>), dim3(tiles_m * tiles_n), dim3(512), 0, st, a, b, D, sa_inv, sb_inv,
                        bp, (int)M, (int)N, (int)K, lda, ldb, ldd, tiles_m, tiles_n);
-  } else if (algo == 4 || (algo >= 15 && algo <= 17) || (algo >= 40 && algo <= 45)) {
+  } else if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 17) || (algo >= 40 && algo <= 45)) {
     return launch_p8<FA, FB>(a, b, (uint16_t*)D, sa_inv, sb_inv, (const uint8_t*)SA, (const uint8_t*)SB, bp, M, N, K, lda, ldb, ldd,
                              algo, mx, st);
   } else if (algo == 13 && !mx) {
@@ -1095,7 +1097,7 @@ static int pick_algo(int algo, int64_t M, int64_t N, int64_t K, int64_t lda, int
   const bool p8_ok = (M % 256 == 0 || M % 192 == 0) && (N % 256 == 0 || N % 192 == 0) && M > 0 && N > 0 && K > 0 &&
                      (K % (2 * BK) == 0) && out == 0 && M * lda < (1LL << 31) && N * ldb < (1LL << 31) &&
                      M * ldd * 2 < (1LL << 31);
-  if (algo == 4 || (algo >= 15 && algo <= 17) || (algo >= 40 && algo <= 45)) {
+  if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 17) || (algo >= 40 && algo <= 45)) {
     if (!p8_ok) {
       set_error("%s: algo %d needs M,N %% 256 (or 192) == 0, K %% 256 == 0, bf16 output, operands < 2 GiB", who, algo);
       return MI_ERR_SHAPE;
@@ -1137,7 +1139,7 @@ extern "C" int mi_gemm_mxfp8(const void* A, const void* SA, const void* B, const
   if (rc != MI_OK) return rc;
   MI_CHECK_ARG(SA && SB, "mi_gemm_mxfp8: null scale pointer");
   MI_CHECK_ARG(K % 32 == 0, "mi_gemm_mxfp8: K must be a multiple of 32");
-  MI_CHECK_ARG(algo == 0 || algo == 1 || algo == 4 || (algo >= 40 && algo <= 45), "mi_gemm_mxfp8: algo must be 0, 1, 4 or 40-45");
+  MI_CHECK_ARG(algo == 0 || algo == 1 || algo == 4 || algo == 5 || (algo >= 40 && algo <= 45), "mi_gemm_mxfp8: algo must be 0, 1, 4, 5 or 40-45");
   if (M == 0 || N == 0) return MI_OK;
   int a = algo == 0 ? 4 : algo;
   if (a != 1) {

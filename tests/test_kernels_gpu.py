@@ -163,14 +163,14 @@ GEMM_SHAPES = [(256, 256, 256), (512, 768, 640), (768, 384, 512), (1536, 1920, 2
 
 @pytest.mark.parametrize("shape", GEMM_SHAPES)
 @pytest.mark.parametrize("fa,fb", [(O.E4M3, O.E4M3), (O.E5M2, O.E4M3), (O.E4M3, O.E5M2), (O.E5M2, O.E5M2)])
-@pytest.mark.parametrize("algo", [0, 1, 2, 3, 4, 41, 42, 43])
+@pytest.mark.parametrize("algo", [0, 1, 2, 3, 4, 5, 41, 42, 43])
 def test_gemm_fp8_vs_oracle(ops, dev, shape, fa, fb, algo):
     M, N, K = shape
     if algo == 1 and M * N * K > 256 * 512 * 3072:
         pytest.skip("generic path covered at smaller sizes")
     if algo in (2, 3) and (M % 256 or N % 256 or K % 128):
         pytest.skip("fast kernels need 256/256/128-aligned shapes")
-    if algo == 4 and ((M % 256 and M % 192) or (N % 256 and N % 192) or K % 256):
+    if algo in (4, 5) and ((M % 256 and M % 192) or (N % 256 and N % 192) or K % 256):
         pytest.skip("persistent kernel needs 256- or 192-aligned M, N and 256-aligned K")
     if algo in (41, 42, 43):
         bm, bn = {41: (256, 192), 42: (192, 256), 43: (192, 192)}[algo]

@@ -70,6 +70,14 @@ def main():
                     tf = 2.0 * m * n * k / t / 1e12
                     print(f"gemm {name:4s} {kind:5s} {m:6d}x{n:6d}x{k:6d} algo {algo}: {t*1e6:9.1f} us {tf:8.1f} TFLOP/s "
                           f"({tf/5000*100:5.1f}% of 5 PF)", flush=True)
+    if "algos" in args.which:  # interleaved A/B of the persistent (4) and the non-persistent 8-phase kernel (3: the default under torch.distributed)
+        for name, (M, N, K) in SHAPES_3B.items():
+            for kind, (m, n, k) in (("fprop", (M, N, K)), ("dgrad", (M, K, N)), ("wgrad", (N, K, M))):
+                a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
+                out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+                fns = {al: (lambda al_: (lambda: ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=al_)))(al) for al in (4, 5, 3)}
+                res = time_interleaved(fns)
+                print(f"algos {name:4s} {kind:5s} {m}x{n}x{k}: " + "  ".join(f"algo {al}: {t*1e6:7.1f} us {2.0*m*n*k/t/1e12:6.0f} TF" for al, t in res.items()), flush=True)
     if "tiles" in args.which:
         for (m, n, k) in ((8192, 3072, 3072), (8192, 3072, 8192), (3072, 8192, 8192), (3072, 3072, 8192), (8192, 3072, 16384),
                           (8192, 6144, 3072), (6144, 6144, 4096), (8192, 3072, 5120), (8192, 5120, 3072), (5120, 3072, 8192)):
