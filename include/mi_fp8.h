@@ -230,6 +230,11 @@ int mi_adamw_bf16(void* p_bf16, const void* g_bf16, void* exp_avg_bf16, void* ex
  */
 int mi_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int S, int H, int G, int D,
                 int64_t q_ts, int64_t k_ts, int64_t v_ts, int64_t o_ts, float scale, int causal, void* stream);
+/* Timing-only diagnostic build of the forward kernel (causal, D = 128): per wave, shader cycles spent in {S^T MFMAs + K fragment
+ * reads, softmax arithmetic, P.V MFMAs + V fragment reads, stage stores incl. the wait for the next tile's loads, barrier};
+ * dbg [B, H, S/128, 4 waves, 8] u64 (slot 5 = tiles walked).  Shares only: the stamps forbid overlaps the real kernel has. */
+int mi_attn_fwd_diag(const void* q, const void* k, const void* v, void* o, float* lse, unsigned long long* dbg, int B, int S,
+                     int H, int G, int D, int64_t q_ts, int64_t k_ts, int64_t v_ts, int64_t o_ts, float scale, void* stream);
 /*
  * Backward of mi_attn_fwd: P is recomputed from q, k and `lse`; two launches (dQ pass, which also writes
  * delta[B, H, S] = rowsum(dO * O), then the dK/dV pass), no sums across workgroups: results are bitwise reproducible.

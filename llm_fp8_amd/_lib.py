@@ -43,6 +43,7 @@ SIGNATURES = {
     "mi_gemm_set_workspace": [_p, _c_i64],
     "mi_attn_fwd": [_p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_i64, ctypes.c_float,
                     _c_int, _p],
+    "mi_attn_fwd_diag": [_p, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_i64, ctypes.c_float, _p],
     "mi_attn_bwd": [_p] * 10 + [_c_int] * 5 + [_c_i64] * 8 + [ctypes.c_float, _c_int, _p],
     "mi_mxfp8_norm_quantize": [_p, _p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],
     "mi_mxfp8_swiglu_quantize": [_p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],

@@ -83,11 +83,12 @@ __device__ __forceinline__ void stage_store(const v4i (&reg)[D / 32], char* tile
   }
 }
 
-template <int D, bool CAUSAL>
+template <int D, bool CAUSAL, bool DIAG = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                           const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
                                                           float* __restrict__ lse, int S, int H, int G, int64_t q_ts,
-                                                          int64_t k_ts, int64_t v_ts, int64_t o_ts, float c) {
+                                                          int64_t k_ts, int64_t v_ts, int64_t o_ts, float c,
+                                                          unsigned long long* __restrict__ dbg = nullptr) {
   constexpr int TILE = ATT_KB * D * 2;  // bytes of one K (or V) tile
   constexpr int KT = D / 16, DB = D / 32;
   __shared__ __attribute__((aligned(16))) char lds[4 * TILE];
@@ -105,6 +106,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
 #pragma unroll
     for (int t = 0; t < KT; ++t) qf[t] = as_bf8(*reinterpret_cast<const v4i*>(qp + 16 * t));
   }
+  // retire the Q loads HERE: left to the compiler they sink below the prologue and their vmcnt waits end up in front of the
+  // loop's first MFMAs, where the in-order counter makes every tile wait for the NEXT tile's just-issued loads as well
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    v4i tmp = __builtin_bit_cast(v4i, qf[t]);
+    asm volatile("" : "+v"(tmp));
+    qf[t] = as_bf8(tmp);
+  }
   f16v oacc[DB];
 #pragma unroll
   for (int d = 0; d < DB; ++d)
@@ -119,6 +128,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
   stage_store<D>(vreg, lds + 2 * TILE, tid);
   __syncthreads();
 
+  unsigned long long tsum[5] = {0, 0, 0, 0, 0}, t_prev = 0;
+#define MI_STAMP(k)                                                                       \
+  if (DIAG) {                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    unsigned long long tn_;                                                               \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn_)::"memory");          \
+    if ((k) >= 0) tsum[(k) < 0 ? 0 : (k)] += tn_ - t_prev;                                  \
+    t_prev = tn_;                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+  }
+  MI_STAMP(-1)
   for (int j = 0; j < ntiles; ++j) {
     const char* kt = lds + (j & 1) * TILE;
     const char* vt = lds + (2 + (j & 1)) * TILE;
@@ -138,6 +158,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
         for (int t = 0; t < KT; ++t)
           sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(kt, 32 * kb, t, lane), qf[t], sacc[kb], 0, 0, 0);
       }
+      if (DIAG) {
+        asm volatile("" : "+v"(sacc[0][0]), "+v"(sacc[1][15]));
+      }
+      MI_STAMP(0)
       if (CAUSAL && key0 + ATT_KB - 1 > q_first) {  // tile touches the diagonal
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -169,6 +193,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
       for (int d = 0; d < DB; ++d)
 #pragma unroll
         for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+      if (DIAG) {
+        asm volatile("" : "+v"(oacc[0][0]), "+v"(sacc[1][15]), "+v"(l));
+      }
+      MI_STAMP(1)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -179,12 +207,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
             oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(vt, 32 * kb + 16 * s, 32 * d, lane), pf, oacc[d], 0, 0, 0);
         }
     }
+    if (DIAG) {
+      asm volatile("" : "+v"(oacc[0][0]), "+v"(oacc[DB - 1][15]));
+    }
+    MI_STAMP(2)
     if (more) {
       stage_store<D>(kreg, lds + ((j + 1) & 1) * TILE, tid);
       stage_store<D>(vreg, lds + (2 + ((j + 1) & 1)) * TILE, tid);
     }
+    MI_STAMP(3)
     __syncthreads();
+    MI_STAMP(4)
   }
+  if (DIAG && dbg != nullptr && lane == 0) {
+    unsigned long long* dp = dbg + ((((int64_t)b * H + head) * gridDim.x + qb) * 4 + w) * 8;
+    for (int i2 = 0; i2 < 5; ++i2) dp[i2] = tsum[i2];
+    dp[5] = (unsigned long long)ntiles;
+  }
+#undef MI_STAMP
 
   l += __shfl_xor(l, 32);
   const float inv = 1.0f / l;
@@ -485,7 +525,7 @@ extern "C" int mi_attn_fwd(const void* q, const void* k, const void* v, void* o,
   hipStream_t st = (hipStream_t)stream;
 #define MI_ATTN_FWD(DD, CC)                                                                                            \
   hipLaunchKernelGGL((mi::attn_fwd_kernel<DD, CC>), grid, block, 0, st, (const uint16_t*)q, (const uint16_t*)k,          \
-                     (const uint16_t*)v, (uint16_t*)o, lse, S, H, G, q_ts, k_ts, v_ts, o_ts, c)
+                     (const uint16_t*)v, (uint16_t*)o, lse, S, H, G, q_ts, k_ts, v_ts, o_ts, c, (unsigned long long*)nullptr)
   if (D == 128) {
     if (causal) MI_ATTN_FWD(128, true); else MI_ATTN_FWD(128, false);
   } else {
@@ -493,6 +533,21 @@ extern "C" int mi_attn_fwd(const void* q, const void* k, const void* v, void* o,
   }
 #undef MI_ATTN_FWD
   MI_CHECK_LAUNCH("mi_attn_fwd launch");
+  return MI_OK;
+}
+
+// timing-only diagnostic build of the forward kernel: per wave, cycles spent in {S^T MFMAs, softmax, P.V MFMAs, stage stores
+// (incl. the wait for the next tile's global loads), barrier}; dbg [B, H, S/128, 4 waves, 8] u64
+extern "C" int mi_attn_fwd_diag(const void* q, const void* k, const void* v, void* o, float* lse, unsigned long long* dbg, int B,
+                                int S, int H, int G, int D, int64_t q_ts, int64_t k_ts, int64_t v_ts, int64_t o_ts, float scale,
+                                void* stream) {
+  MI_CHECK_ARG(q && k && v && o && lse && dbg, "mi_attn_fwd_diag: null pointer");
+  MI_CHECK_ARG(D == 128 && S % 128 == 0 && H % G == 0, "mi_attn_fwd_diag: unsupported shape");
+  dim3 grid(S / mi::ATT_QB, H, B), block(256);
+  hipLaunchKernelGGL((mi::attn_fwd_kernel<128, true, true>), grid, block, 0, (hipStream_t)stream, (const uint16_t*)q,
+                     (const uint16_t*)k, (const uint16_t*)v, (uint16_t*)o, lse, S, H, G, q_ts, k_ts, v_ts, o_ts,
+                     scale * 1.4426950408889634f, dbg);
+  MI_CHECK_LAUNCH("mi_attn_fwd_diag launch");
   return MI_OK;
 }
 
