@@ -63,6 +63,16 @@ __device__ __forceinline__ bf8 acc_frag(const f16v& a, int s) {
 
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
+// Make a prologue load complete HERE (a use the compiler cannot move): left alone, such loads sink towards their first use
+// inside the tile loop, and the s_waitcnt vmcnt placed there also waits -- the counter is in-order -- for the NEXT tile's
+// just-issued prefetch loads, every tile.
+__device__ __forceinline__ void retire(bf8& f) {
+  v4i tmp = __builtin_bit_cast(v4i, f);
+  asm volatile("" : "+v"(tmp));
+  f = as_bf8(tmp);
+}
+__device__ __forceinline__ void retire(float& f) { asm volatile("" : "+v"(f)); }
+
 constexpr int ATT_QB = 128;  // query rows per workgroup (4 waves x 32)
 constexpr int ATT_KB = 64;   // keys per tile
 
@@ -109,11 +119,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
   // retire the Q loads HERE: left to the compiler they sink below the prologue and their vmcnt waits end up in front of the
   // loop's first MFMAs, where the in-order counter makes every tile wait for the NEXT tile's just-issued loads as well
 #pragma unroll
-  for (int t = 0; t < KT; ++t) {
-    v4i tmp = __builtin_bit_cast(v4i, qf[t]);
-    asm volatile("" : "+v"(tmp));
-    qf[t] = as_bf8(tmp);
-  }
+  for (int t = 0; t < KT; ++t) retire(qf[t]);
   f16v oacc[DB];
 #pragma unroll
   for (int d = 0; d < DB; ++d)
@@ -322,7 +328,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
   dl += __shfl_xor(dl, 32);
   const int64_t stat = ((int64_t)b * H + head) * S + qrow;
   if (h == 0) delta[stat] = dl;
-  const float my_lse = lse[stat];
+  float my_lse = lse[stat];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    retire(qf[t]);
+    retire(dof[t]);
+  }
+  retire(my_lse);
+  retire(dl);
 
   f16v acc[DB];
 #pragma unroll
@@ -416,6 +429,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
       kf[t] = as_bf8(*reinterpret_cast<const v4i*>(kp + 16 * t));
       vf[t] = as_bf8(*reinterpret_cast<const v4i*>(vp + 16 * t));
     }
+  }
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    retire(kf[t]);
+    retire(vf[t]);
   }
   f16v dka[DB], dva[DB];
 #pragma unroll
