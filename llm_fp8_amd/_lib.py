@@ -35,6 +35,9 @@ SIGNATURES = {
     "mi_ce_forward": [_p, _p, _p, _p, _c_i64, _c_i64, _p],
     "mi_ce_backward": [_p, _p, _p, _p, _p, _c_i64, _c_i64, _p],
     "mi_sumsq_bf16": [_p, _c_i64, _p, _c_int, _p],
+    "mi_sumsq_bf16_multi": [_p, _c_int, _p, _c_int, _c_int, _p, _p],
+    "mi_adamw_bf16_multi": [_p, _c_int, _p, _c_int, _c_int, _p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                            ctypes.c_float, _c_i64, _p],
     "mi_adamw_bf16": [_p, _p, _p, _p, _c_i64, _p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                       ctypes.c_float, _c_i64, _p],
     "mi_cast_amax_colsum": [_p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _p],

@@ -109,7 +109,143 @@ __global__ __launch_bounds__(256) void adamw_kernel(uint16_t* __restrict__ p, co
   }
 }
 
+// ---- multi-tensor forms: ONE launch over every tensor of a parameter group.  `tab` [5, T] int64 on the device: rows of
+// p / g / exp_avg / exp_avg_sq addresses and element counts; `chunks` [nchunks] = (tensor index, chunk index inside it); a
+// workgroup owns one chunk of `chunk_elems` elements.  (A 3B model has ~280 parameter tensors: 2 x 280 launches per step,
+// most of them a few microseconds long, become 2.)
+struct ChunkRef {
+  int tensor, chunk;
+};
+
+__global__ __launch_bounds__(256) void sumsq_multi_kernel(const int64_t* __restrict__ tab, int T, const ChunkRef* __restrict__ chunks,
+                                                          int chunk_elems, float* __restrict__ partial) {
+  __shared__ float s_red[4];
+  const ChunkRef cr = chunks[blockIdx.x];
+  const uint16_t* g = reinterpret_cast<const uint16_t*>(tab[(int64_t)1 * T + cr.tensor]);
+  const int64_t n = tab[(int64_t)4 * T + cr.tensor];
+  const int64_t lo = (int64_t)cr.chunk * chunk_elems, hi = min(n, lo + chunk_elems);
+  const int tid = threadIdx.x;
+  float acc0 = 0.0f, acc1 = 0.0f;
+  if ((((uintptr_t)g) & 15) == 0) {  // chunk_elems is a multiple of 8: chunk starts stay 16-byte aligned
+    const int64_t v0 = lo >> 3, v1 = hi >> 3;
+    int64_t i = v0 + tid;
+    for (; i + 256 < v1; i += 512) {
+      const v4i a = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(g) + i);
+      const v4i b = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(g) + i + 256);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32 wa = (u32)a[j], wb = (u32)b[j];
+        const float a0 = __uint_as_float(wa << 16), a1 = __uint_as_float(wa & 0xFFFF0000u);
+        const float b0 = __uint_as_float(wb << 16), b1 = __uint_as_float(wb & 0xFFFF0000u);
+        acc0 += a0 * a0 + a1 * a1;
+        acc1 += b0 * b0 + b1 * b1;
+      }
+    }
+    for (; i < v1; i += 256) {
+      const v4i a = reinterpret_cast<const v4i*>(g)[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32 wa = (u32)a[j];
+        const float a0 = __uint_as_float(wa << 16), a1 = __uint_as_float(wa & 0xFFFF0000u);
+        acc0 += a0 * a0 + a1 * a1;
+      }
+    }
+    for (int64_t k = (v1 << 3) + tid; k < hi; k += 256) {
+      const float a = bf16_bits_to_float(g[k]);
+      acc0 += a * a;
+    }
+  } else {
+    for (int64_t k = lo + tid; k < hi; k += 256) {
+      const float a = bf16_bits_to_float(g[k]);
+      acc0 += a * a;
+    }
+  }
+  float acc = acc0 + acc1;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((tid & 63) == 0) s_red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) partial[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const int64_t* __restrict__ tab, int T, const ChunkRef* __restrict__ chunks,
+                                                          int chunk_elems, const float* __restrict__ grad_scale, AdamArgs a) {
+  const ChunkRef cr = chunks[blockIdx.x];
+  uint16_t* p = reinterpret_cast<uint16_t*>(tab[cr.tensor]);
+  const uint16_t* g = reinterpret_cast<const uint16_t*>(tab[(int64_t)1 * T + cr.tensor]);
+  uint16_t* m = reinterpret_cast<uint16_t*>(tab[(int64_t)2 * T + cr.tensor]);
+  uint16_t* v = reinterpret_cast<uint16_t*>(tab[(int64_t)3 * T + cr.tensor]);
+  const int64_t n = tab[(int64_t)4 * T + cr.tensor];
+  const int64_t lo = (int64_t)cr.chunk * chunk_elems, hi = min(n, lo + chunk_elems);
+  const float gs = grad_scale ? *grad_scale : 1.0f;
+  const int tid = threadIdx.x;
+  const bool aligned = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
+  int64_t done = lo;
+  if (aligned) {
+    const int64_t v0 = lo >> 3, v1 = hi >> 3;
+    for (int64_t i = v0 + tid; i < v1; i += 256) {
+      v4i pv = reinterpret_cast<const v4i*>(p)[i];
+      const v4i gv = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(g) + i);
+      v4i mv = reinterpret_cast<const v4i*>(m)[i];
+      v4i vv = reinterpret_cast<const v4i*>(v)[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float pl = __uint_as_float((u32)pv[j] << 16), ph = __uint_as_float((u32)pv[j] & 0xFFFF0000u);
+        const float gl = gs * __uint_as_float((u32)gv[j] << 16), gh = gs * __uint_as_float((u32)gv[j] & 0xFFFF0000u);
+        float ml = __uint_as_float((u32)mv[j] << 16), mh = __uint_as_float((u32)mv[j] & 0xFFFF0000u);
+        float vl = __uint_as_float((u32)vv[j] << 16), vh = __uint_as_float((u32)vv[j] & 0xFFFF0000u);
+        adam_one(pl, gl, ml, vl, a);
+        adam_one(ph, gh, mh, vh, a);
+        pv[j] = (int)pack_bf16x2(pl, ph);
+        mv[j] = (int)pack_bf16x2(ml, mh);
+        vv[j] = (int)pack_bf16x2(vl, vh);
+      }
+      reinterpret_cast<v4i*>(p)[i] = pv;
+      reinterpret_cast<v4i*>(m)[i] = mv;
+      reinterpret_cast<v4i*>(v)[i] = vv;
+    }
+    done = v1 << 3;
+  }
+  for (int64_t k = done + tid; k < hi; k += 256) {
+    float pf = bf16_bits_to_float(p[k]), mf = bf16_bits_to_float(m[k]), vf = bf16_bits_to_float(v[k]);
+    adam_one(pf, gs * bf16_bits_to_float(g[k]), mf, vf, a);
+    p[k] = (uint16_t)float_to_bf16_bits(pf);
+    m[k] = (uint16_t)float_to_bf16_bits(mf);
+    v[k] = (uint16_t)float_to_bf16_bits(vf);
+  }
+}
+
 }  // namespace mi
+
+static mi::AdamArgs make_adam_args(float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step) {
+  mi::AdamArgs a;
+  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  a.step_size = (float)((double)lr / bc1);
+  a.bc2_sqrt = (float)sqrt(bc2);
+  return a;
+}
+
+extern "C" int mi_sumsq_bf16_multi(const int64_t* table, int n_tensors, const int32_t* chunks, int n_chunks, int chunk_elems,
+                                   float* partial, void* stream) {
+  MI_CHECK_ARG(table && chunks && partial, "mi_sumsq_bf16_multi: null pointer");
+  MI_CHECK_ARG(n_tensors >= 1 && n_chunks >= 1 && chunk_elems >= 8 && chunk_elems % 8 == 0, "mi_sumsq_bf16_multi: bad sizes");
+  hipLaunchKernelGGL(mi::sumsq_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, table, n_tensors,
+                     (const mi::ChunkRef*)chunks, chunk_elems, partial);
+  MI_CHECK_LAUNCH("mi_sumsq_bf16_multi launch");
+  return MI_OK;
+}
+
+extern "C" int mi_adamw_bf16_multi(const int64_t* table, int n_tensors, const int32_t* chunks, int n_chunks, int chunk_elems,
+                                   const float* grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                   int64_t step, void* stream) {
+  MI_CHECK_ARG(table && chunks, "mi_adamw_bf16_multi: null pointer");
+  MI_CHECK_ARG(n_tensors >= 1 && n_chunks >= 1 && chunk_elems >= 8 && chunk_elems % 8 == 0 && step >= 1, "mi_adamw_bf16_multi: bad sizes");
+  hipLaunchKernelGGL(mi::adamw_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, table, n_tensors,
+                     (const mi::ChunkRef*)chunks, chunk_elems, grad_scale, make_adam_args(lr, beta1, beta2, eps, weight_decay, step));
+  MI_CHECK_LAUNCH("mi_adamw_bf16_multi launch");
+  return MI_OK;
+}
 
 extern "C" int mi_sumsq_bf16(const void* g_bf16, int64_t n, float* partial, int n_partials, void* stream) {
   MI_CHECK_ARG(g_bf16 && partial, "mi_sumsq_bf16: null pointer");
@@ -125,11 +261,7 @@ extern "C" int mi_adamw_bf16(void* p_bf16, const void* g_bf16, void* exp_avg_bf1
   MI_CHECK_ARG(p_bf16 && g_bf16 && exp_avg_bf16 && exp_avg_sq_bf16, "mi_adamw_bf16: null pointer");
   MI_CHECK_ARG(n >= 0 && step >= 1, "mi_adamw_bf16: bad n / step");
   if (n == 0) return MI_OK;
-  mi::AdamArgs a;
-  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
-  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  a.step_size = (float)((double)lr / bc1);
-  a.bc2_sqrt = (float)sqrt(bc2);
+  const mi::AdamArgs a = make_adam_args(lr, beta1, beta2, eps, weight_decay, step);
   int64_t blocks = ((n >> 3) + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 4096) blocks = 4096;

@@ -1,6 +1,7 @@
 """`ClippedAdamW`: the reference's `clip_grad_norm_(params, max_norm)` + `AdamW(fused=True).step()` pair
 (train_fp8.py:288-291) as two streaming HIP passes: one reproducible squared-norm reduction over the gradients and one
-AdamW update with the clip coefficient folded in (the gradients are never rescaled in place).  bf16 parameters with bf16
+AdamW update with the clip coefficient folded in (the gradients are never rescaled in place), each ONE multi-tensor launch
+per parameter group (device tables of tensor addresses + a chunk list).  bf16 parameters with bf16
 `exp_avg` / `exp_avg_sq`, fp32 math -- the state layout of torch's fused AdamW, so `state_dict()` is interchangeable."""
 from __future__ import annotations
 
@@ -16,7 +17,7 @@ class ClippedAdamW(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.max_grad_norm = max_grad_norm
-        self._partials = None
+        self._plans = {}
         self.last_grad_norm: Optional[torch.Tensor] = None
 
     def _grads(self):
@@ -29,6 +30,40 @@ class ClippedAdamW(torch.optim.Optimizer):
                     out.append((group, p))
         return out
 
+    CHUNK = 65536  # elements per workgroup of the multi-tensor kernels (128 KiB of bf16)
+
+    def _plan(self, group_items, dev):
+        """Device tables of one parameter group for the multi-tensor kernels.  The chunk list only depends on the tensor sizes
+        and is built once; the address table is re-uploaded when an address changed (gradients are new tensors every step,
+        though the caching allocator usually hands back the same blocks)."""
+        key = id(group_items[0][0])
+        sizes = tuple(p.numel() for _, p in group_items)
+        plan = self._plans.get(key)
+        if plan is None or plan["sizes"] != sizes:
+            refs = []
+            for t, n in enumerate(sizes):
+                refs.extend((t, c) for c in range((n + self.CHUNK - 1) // self.CHUNK))
+            chunks = torch.tensor(refs, dtype=torch.int32).to(dev)
+            plan = {"sizes": sizes, "chunks": chunks, "n_chunks": len(refs), "addr": None,
+                    "table": torch.empty((5, len(sizes)), dtype=torch.int64, device=dev),
+                    "host": [torch.empty((5, len(sizes)), dtype=torch.int64).pin_memory() for _ in range(2)], "flip": 0,
+                    "partials": torch.empty(len(refs), dtype=torch.float32, device=dev)}
+            self._plans[key] = plan
+        rows = [[], [], [], [], list(sizes)]
+        for _, p in group_items:
+            st = self.state[p]
+            rows[0].append(p.data_ptr())
+            rows[1].append(p.grad.data_ptr())
+            rows[2].append(st["exp_avg"].data_ptr())
+            rows[3].append(st["exp_avg_sq"].data_ptr())
+        if plan["addr"] != rows:
+            host = plan["host"][plan["flip"]]  # two pinned staging buffers: the previous async copy may still be in flight
+            plan["flip"] ^= 1
+            host.copy_(torch.tensor(rows, dtype=torch.int64))
+            plan["table"].copy_(host, non_blocking=True)
+            plan["addr"] = rows
+        return plan
+
     @torch.no_grad()
     def step(self, closure=None):
         assert closure is None
@@ -38,35 +73,38 @@ class ClippedAdamW(torch.optim.Optimizer):
         lib = _lib.load()
         dev = items[0][1].device
         st = torch.cuda.current_stream().cuda_stream
-        coef_ptr = None
-        if self.max_grad_norm is not None:
-            # one partial per 8 Ki elements (at most 2048 per tensor, 8 workgroups per CU): tiny tensors cost one workgroup
-            nblks = [max(1, min(2048, (p.numel() + 8191) // 8192)) for _, p in items]
-            need = sum(nblks)
-            if self._partials is None or self._partials.numel() < need or self._partials.device != dev:
-                self._partials = torch.empty(need, dtype=torch.float32, device=dev)
-            part = self._partials[:need]
-            off = 0
-            for (_, p), nb in zip(items, nblks):
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                _lib.check(lib.mi_sumsq_bf16(g.data_ptr(), g.numel(), part[off:].data_ptr(), nb, st), "mi_sumsq_bf16")
-                off += nb
-            total = part.sum(dtype=torch.float32).sqrt()
-            self.last_grad_norm = total
-            coef = (self.max_grad_norm / (total + 1e-6)).clamp(max=1.0).reshape(1)  # clip_grad_norm_'s coefficient
-            coef_ptr = coef.data_ptr()
+        by_group = {}
         for group, p in items:
             state = self.state[p]
             if not state:
                 state["step"] = 0
                 state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            state["step"] += 1
-            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            if not p.grad.is_contiguous():
+                p.grad = p.grad.contiguous()
             assert p.is_contiguous()
+            by_group.setdefault((id(group), state["step"]), []).append((group, p))
+        plans = [(gi, self._plan(gi, dev)) for gi in by_group.values()]
+        coef_ptr = None
+        if self.max_grad_norm is not None:
+            # squared norm: one launch per parameter group, one fp32 partial per 64 Ki-element chunk, fixed summation order
+            for gi, plan in plans:
+                _lib.check(lib.mi_sumsq_bf16_multi(plan["table"].data_ptr(), len(gi), plan["chunks"].data_ptr(), plan["n_chunks"],
+                                                   self.CHUNK, plan["partials"].data_ptr(), st), "mi_sumsq_bf16_multi")
+            total = plans[0][1]["partials"].sum(dtype=torch.float32)
+            for _, plan in plans[1:]:
+                total = total + plan["partials"].sum(dtype=torch.float32)
+            total = total.sqrt()
+            self.last_grad_norm = total
+            coef = (self.max_grad_norm / (total + 1e-6)).clamp(max=1.0).reshape(1)  # clip_grad_norm_'s coefficient
+            coef_ptr = coef.data_ptr()
+        for gi, plan in plans:
+            group = gi[0][0]
+            for _, p in gi:
+                self.state[p]["step"] += 1
             b1, b2 = group["betas"]
-            rc = lib.mi_adamw_bf16(p.data_ptr(), g.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
-                                   p.numel(), coef_ptr, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
-                                   int(state["step"]), st)
-            _lib.check(rc, "mi_adamw_bf16")
+            rc = lib.mi_adamw_bf16_multi(plan["table"].data_ptr(), len(gi), plan["chunks"].data_ptr(), plan["n_chunks"], self.CHUNK,
+                                         coef_ptr, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
+                                         int(self.state[gi[0][1]]["step"]), st)
+            _lib.check(rc, "mi_adamw_bf16_multi")
         return None
