@@ -46,6 +46,12 @@ __device__ __forceinline__ v4f mfma_ba(const v8i& a, const v8i& b, v4f acc, int 
   return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b, a, acc, FB, FA, 0, sb, 0, sa);
 }
 
+// same, the A-side scale taken from byte OPS of `sa` (one dword holds the scales of a lane's 4 row-interleaved fragments)
+template <int FA, int FB, int OPS>
+__device__ __forceinline__ v4f mfma_ba_sel(const v8i& a, const v8i& b, v4f acc, int sa, int sb) {
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b, a, acc, FB, FA, 0, sb, OPS, sa);
+}
+
 __device__ __forceinline__ int swz_f(int row) { return ((row >> 1) & 3) << 1; }  // depends on row & 7 only
 
 // ------------------------------------------------------------------------------------------------
@@ -499,12 +505,21 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   constexpr int RA0 = 64, RA1 = 16 * MA1, RB0 = 32, RB1 = 16 * NB1;  // rows of A / B per wave in half 0 / 1
   constexpr int TBM = 2 * (RA0 + RA1), TBN = 4 * (RB0 + RB1);        // workgroup tile
   constexpr int nA1 = MA1 / 2, nB1 = NB1;                            // LDS-DMA pieces per wave of the second halves
-  constexpr int EX = (MX ? 1 : 0) + (BIAS ? 1 : 0);                  // extra LDS-DMA ops per K-tile (head of phase 0)
+  // extra LDS-DMA ops per K-tile at the head of phase 0: the bias window and, for MX, one 256-byte run of block scales per
+  // wave (waves 0-3: k-block w of A for the NEXT step; waves 4-7: k-block w-4 of B for the step AFTER next).  B runs two
+  // steps ahead because its stagers are wave group 1, a phase BEHIND group 0: one step ahead, group 0 read the B scales
+  // before the barrier that follows the stagers' wait -- a race seen as run-to-run differences of the mxfp8 loss.
+  constexpr int EX = (MX ? 1 : 0) + (BIAS ? 1 : 0);
   constexpr int W = nA1 + nB1 + 4;                                   // younger ops allowed at the p3 wait (8 for 256x256)
   constexpr int NST = (4 + MA1) * 2;                                 // epilogue stores per wave and tile
-  // behind the operand buffers: 4 KiB of E8M0 scales (MX: 2 slots x {A, B} x 4 k-blocks x 256 rows) and 4 KiB of
+  // MX: the A fragments of a half are ROW-INTERLEAVED (fragment i, lane row-slot s <-> row F*s + i of the half, F = its
+  // fragment count) instead of blocked (16*i + s): the F block scales a lane needs per k-block are then F consecutive bytes,
+  // one LDS read instead of F byte reads (12 ds_read_u8 per K-tile cost the block-scaled GEMM 10 %).  Free on both sides:
+  // the rows are gathered by the LDS-DMA source addresses, and an epilogue store covers 16 rows either way.
+  constexpr bool PERM = MX;
+  // behind the operand buffers: 6 KiB for the E8M0 scales (MX: 2 slots x {A, B} x 4 k-blocks x 256 rows, padded) and 4 KiB of
   // bias windows (BIAS: 2 slots x 8 waves x 256 B)
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes + ((MX || BIAS) ? 8192 : 0)];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes + ((MX || BIAS) ? 10240 : 0)];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -531,18 +546,24 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   const bool s_is_b = wave >= 4;
   const int s_rows = s_is_b ? N : M;
   const rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(MX ? (s_is_b ? SB : SA) : A), 0, MX ? (K / 32) * s_rows : 0, 0x00020000);
-  uint8_t* const sbuf = lds + kLdsBytes;  // [slot][operand][4][256]
-  auto stage_scales = [&](int slot, int kt, int row0a, int row0b) {
+  // [slot][operand][4 k-blocks][256 rows], the k-block rows 272 B apart: the four 16-lane groups of a scale read (k-blocks
+  // 0..3 of rows r..r+15) then fall on disjoint banks; at a 256-B stride they were a 4-way conflict on an LDS that the
+  // fragment reads already keep 75 % busy, and the block-scaled GEMM ran 10 % behind the per-tensor one
+  // LDS: A scales [2 slots][4 k-blocks][272] then B scales [3 slots][4][272]
+  constexpr int kSK = 272, kSOp = 4 * kSK, kSB = 2 * kSOp;
+  uint8_t* const sbuf = lds + kLdsBytes;
+  // one op per wave: A scales of (slot_a, K-tile kt_a, rows from row_a) or B scales of (slot_b, kt_b, row_b)
+  auto stage_scales = [&](int slot_a, int kt_a, int row_a, int slot_b, int kt_b, int row_b) {
     if (MX) {
-      const int soff = (kt * 4 + (wave & 3)) * s_rows + (s_is_b ? row0b : row0a);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, LDS_PTR(sbuf + slot * 2048 + (wave >> 2) * 1024 + (wave & 3) * 256), 4,
-                                               lane * 4, soff, 0, 0);
+      const int soff = s_is_b ? (kt_b * 4 + (wave & 3)) * N + row_b : (kt_a * 4 + wave) * M + row_a;
+      uint8_t* dst = s_is_b ? sbuf + kSB + slot_b * kSOp + (wave & 3) * kSK : sbuf + slot_a * kSOp + wave * kSK;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, LDS_PTR(dst), 4, lane * 4, soff, 0, 0);
     }
   };
   // bias: every K-tile each wave re-fetches the 256-byte window that starts at its own columns of cursor 1's tile
   // (one dword per lane; reads past N return 0 through the descriptor's range check) -> uniform vmcnt accounting
   const rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)(BIAS ? (const void*)bias : (const void*)A), 0, BIAS ? N * 2 : 0, 0x00020000);
-  uint8_t* const bbuf = lds + kLdsBytes + 4096;  // [slot][wave][256 B]
+  uint8_t* const bbuf = lds + kLdsBytes + 6144;  // [slot][wave][256 B]
   auto stage_bias = [&](int slot, int col0) {
     if (BIAS)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBias, LDS_PTR(bbuf + (slot * 8 + wave) * 256), 4, lane * 4,
@@ -567,13 +588,15 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int local = (wave * 2 + i) * 8 + lr;  // half 0: 128 rows, 16 pieces
-      a0_voff[i] = ((local / RA0) * (RA0 + RA1) + local % RA0) * lda + chunk;
+      const int l0 = local % RA0;
+      a0_voff[i] = ((local / RA0) * (RA0 + RA1) + (PERM ? 4 * (l0 & 15) + (l0 >> 4) : l0)) * lda + chunk;
       b0_voff[i] = ((local / RB0) * (RB0 + RB1) + local % RB0) * ldb + chunk;
     }
 #pragma unroll
     for (int i = 0; i < nA1; ++i) {
       const int local = (wave * nA1 + i) * 8 + lr;  // half 1 of A: 2*RA1 rows
-      a1_voff[i] = ((local / RA1) * (RA0 + RA1) + RA0 + local % RA1) * lda + chunk;
+      const int l1 = local % RA1;
+      a1_voff[i] = ((local / RA1) * (RA0 + RA1) + RA0 + (PERM ? MA1 * (l1 & 15) + (l1 >> 4) : l1)) * lda + chunk;
     }
 #pragma unroll
     for (int i = 0; i < nB1; ++i) {
@@ -621,7 +644,8 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   uint8_t* const buf1 = lds + kBufBytes;
   // prologue: step 0 complete, (step 1: A0, B0) in flight
   const int kb0 = SK ? sk_k0 * BK : 0;  // first step's K offset (bytes)
-  stage_scales(0, SK ? sk_k0 : 0, ra_0, rb_0);
+  stage_scales(0, SK ? sk_k0 : 0, ra_0, 0, SK ? sk_k0 : 0, rb_0);  // step 0: A (waves 0-3) and B (waves 4-7)
+  if (MX && s_is_b) stage_scales(0, 0, 0, 1, kt_1, rb_1);          // B scales of step 1 (B is staged two steps ahead)
   stage_bias(0, rb_0);
   stage_n<2>(rsA, a0_voff, oa_0 + kb0, buf0 + kOffA0, wave);
   stage_n<2>(rsB, b0_voff, ob_0 + kb0, buf0 + kOffB0, wave);
@@ -641,8 +665,10 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
 
   v8i af[4], b0f[2], b1f[2];
   int as_[4] = {kUnitScale, kUnitScale, kUnitScale, kUnitScale}, b0s[2] = {kUnitScale, kUnitScale}, b1s[2] = {kUnitScale, kUnitScale};
+  int as1[4] = {kUnitScale, kUnitScale, kUnitScale, kUnitScale};  // scales of the A1 half (phases 2-3)
   const int sfr = lane & 15, sfq = lane >> 4;
-  int s = 0;  // current step
+  int s = 0;      // current step
+  int bslot = 0;  // B-scale slot of the current step (step % 3)
   // One K-tile = 4 phases.  Waits: phases 0-2 allow W + EX younger LDS-DMA ops, phase 3 allows W; `after_epi`
   // (uniform): first K-tile behind an epilogue, whose NST stores sit between the awaited loads and the younger ones.
 #define MI_WAIT_SYNC(after_epi, P3)                                    \
@@ -655,8 +681,20 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
 #define MI_PIN(NI, NJ, EXPR)                                           \
   _Pragma("unroll") for (int i = 0; i < NI; ++i)                       \
   _Pragma("unroll") for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(EXPR));
+  // fragment i of an A half: per-fragment scale register (per-tensor path, unit scales) or byte i of the packed one (MX)
+  auto mfma_sel = [&](int i, const v8i& a_, const v8i& b_, v4f c_, const int (&sa_)[4], int sb_) -> v4f {
+    if (!PERM) return mfma_ba<FA, FB>(a_, b_, c_, sa_[i], sb_);
+    switch (i) {
+      case 0: return mfma_ba_sel<FA, FB, 0>(a_, b_, c_, sa_[0], sb_);
+      case 1: return mfma_ba_sel<FA, FB, 1>(a_, b_, c_, sa_[0], sb_);
+      case 2: return mfma_ba_sel<FA, FB, 2>(a_, b_, c_, sa_[0], sb_);
+      default: return mfma_ba_sel<FA, FB, 3>(a_, b_, c_, sa_[0], sb_);
+    }
+  };
   auto ktile = [&](uint8_t* cur, uint8_t* oth, bool after_epi, int slot) {
-    const uint8_t* sc = sbuf + slot * 2048 + sfq * 256 + sfr;  // + operand*1024 + tile row of the fragment
+    const uint8_t* sc = sbuf + slot * kSOp + sfq * kSK + sfr;            // A scales: + tile row of the fragment
+    const uint8_t* scb = sbuf + kSB + bslot * kSOp + sfq * kSK + sfr;   // B scales of this step
+    const int bslot2 = bslot == 0 ? 2 : bslot - 1;                      // (bslot + 2) % 3: target of the step after next
     const int sa1 = oa_1 + kt_1 * BK, sb1 = ob_1 + kt_1 * BK;
     const int sa2 = oa_2 + kt_2 * BK, sb2 = ob_2 + kt_2 * BK;
     // ---- phase 0: C[0][*][0][*]
@@ -664,50 +702,57 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
     for (int j = 0; j < 2; ++j) b0f[j] = read_frag(cur + kOffB0, wc * 2 + j, lane);
 #pragma unroll
     for (int i = 0; i < 4; ++i) af[i] = read_frag(cur + kOffA0, wr * 4 + i, lane);
-    if (MX) {
+    if (MX && ABL != 5) {  // every scale of this K-tile up front: phases 1-3 then start on their fragment reads alone
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b0s[j] = sc[1024 + wc * (RB0 + RB1) + j * 16];
+      for (int j = 0; j < 2; ++j) b0s[j] = scb[wc * (RB0 + RB1) + j * 16];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) as_[i] = sc[wr * (RA0 + RA1) + i * 16];
+      for (int j = 0; j < NB1; ++j) b1s[j] = scb[wc * (RB0 + RB1) + RB0 + j * 16];
+      // A side: the lane's 4 (A0) and MA1 (A1) fragment scales as one dword / one u16 (sfr = row slot, see PERM)
+      as_[0] = *reinterpret_cast<const int*>(sc - sfr + wr * (RA0 + RA1) + 4 * sfr);
+      if (MA1 == 4) as1[0] = *reinterpret_cast<const int*>(sc - sfr + wr * (RA0 + RA1) + RA0 + 4 * sfr);
+      else as1[0] = *reinterpret_cast<const uint16_t*>(sc - sfr + wr * (RA0 + RA1) + RA0 + 2 * sfr);
+      if (ABL == 6) {  // timing ablation: the scales are read but the MFMAs get unit scales
+        asm volatile("" ::"v"(as_[0]), "v"(as1[0]));
+        as_[0] = kUnitScale;
+        as1[0] = kUnitScale;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          asm volatile("" ::"v"(b0s[j]), "v"(b1s[j]));
+          b0s[j] = kUnitScale;
+          b1s[j] = kUnitScale;
+        }
+      }
     }
-    stage_scales(slot ^ 1, kt_1, ra_1, rb_1);
+    stage_scales(slot ^ 1, kt_1, ra_1, bslot2, kt_2, rb_2);
     stage_bias(ti_1 & 1, rb_1);
     stage_n<nB1>(rsB, b1_voff, sb1, oth + kOffB1, wave);
     MI_WAIT_SYNC(after_epi, false)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[0][i][0][j] = mfma_ba<FA, FB>(af[i], b0f[j], acc[0][i][0][j], as_[i], b0s[j]);
+      for (int j = 0; j < 2; ++j) acc[0][i][0][j] = mfma_sel(i, af[i], b0f[j], acc[0][i][0][j], as_, b0s[j]);
     MI_PIN(4, 2, acc[0][i][0][j])
     MI_PHASE_END();
     // ---- phase 1: C[0][*][1][*]
 #pragma unroll
     for (int j = 0; j < NB1; ++j) b1f[j] = read_frag(cur + kOffB1, wc * NB1 + j, lane);
-    if (MX) {
-#pragma unroll
-      for (int j = 0; j < NB1; ++j) b1s[j] = sc[1024 + wc * (RB0 + RB1) + RB0 + j * 16];
-    }
     stage_n<nA1>(rsA, a1_voff, sa1, oth + kOffA1, wave);
     MI_WAIT_SYNC(after_epi, false)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < NB1; ++j) acc[0][i][1][j] = mfma_ba<FA, FB>(af[i], b1f[j], acc[0][i][1][j], as_[i], b1s[j]);
+      for (int j = 0; j < NB1; ++j) acc[0][i][1][j] = mfma_sel(i, af[i], b1f[j], acc[0][i][1][j], as_, b1s[j]);
     MI_PIN(4, NB1, acc[0][i][1][j])
     MI_PHASE_END();
     // ---- phase 2: C[1][*][1][*]
 #pragma unroll
     for (int i = 0; i < MA1; ++i) af[i] = read_frag(cur + kOffA1, wr * MA1 + i, lane);
-    if (MX) {
-#pragma unroll
-      for (int i = 0; i < MA1; ++i) as_[i] = sc[wr * (RA0 + RA1) + RA0 + i * 16];
-    }
     stage_n<2>(rsA, a0_voff, sa2, cur + kOffA0, wave);
     MI_WAIT_SYNC(after_epi, false)
 #pragma unroll
     for (int i = 0; i < MA1; ++i)
 #pragma unroll
-      for (int j = 0; j < NB1; ++j) acc[1][i][1][j] = mfma_ba<FA, FB>(af[i], b1f[j], acc[1][i][1][j], as_[i], b1s[j]);
+      for (int j = 0; j < NB1; ++j) acc[1][i][1][j] = mfma_sel(i, af[i], b1f[j], acc[1][i][1][j], as1, b1s[j]);
     MI_PIN(MA1, NB1, acc[1][i][1][j])
     MI_PHASE_END();
     // ---- phase 3: C[1][*][0][*]
@@ -716,10 +761,11 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
 #pragma unroll
     for (int i = 0; i < MA1; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[1][i][0][j] = mfma_ba<FA, FB>(af[i], b0f[j], acc[1][i][0][j], as_[i], b0s[j]);
+      for (int j = 0; j < 2; ++j) acc[1][i][0][j] = mfma_sel(i, af[i], b0f[j], acc[1][i][0][j], as1, b0s[j]);
     MI_PIN(MA1, 2, acc[1][i][0][j])
     MI_PHASE_END();
     // cursors follow the step
+    bslot = bslot == 2 ? 0 : bslot + 1;
     ++s;
     advance(ti_1, kt_1, oa_1, ob_1, ra_1, rb_1, s + 1);
     advance(ti_2, kt_2, oa_2, ob_2, ra_2, rb_2, s + 2);
@@ -727,7 +773,8 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
 
   const int fr = lane & 15, fq = lane >> 4;
   const int ecol = (fq & 1) * 16 + (fq >> 1) * 8;  // column of this lane's 8-wide piece after the permlane16 swap
-  const int d_voff = ((wr * (RA0 + RA1) + fr) * ldd + wc * (RB0 + RB1)) * 2;  // bytes, within the tile
+  const int d_voff = ((wr * (RA0 + RA1) + (PERM ? 4 : 1) * fr) * ldd + wc * (RB0 + RB1)) * 2;  // bytes, within the tile (half 0)
+  const int d_voff1 = (PERM && MA1 != 4) ? ((wr * (RA0 + RA1) + MA1 * fr) * ldd + wc * (RB0 + RB1)) * 2 : d_voff;  // half 1
   auto epilogue = [&](int ti) {
     int tm, tn;
     tile_mn(ti, tm, tn);
@@ -752,7 +799,8 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
       for (int i = 0; i < (a == 0 ? 4 : MA1); ++i)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          const int soff = d_tile + ((a * RA0 + i * 16) * ldd + b * RB0) * 2;
+          const int soff = d_tile + ((a * RA0 + (PERM ? i : i * 16)) * ldd + b * RB0) * 2;
+          const int dvo = a == 0 ? d_voff : d_voff1;
           if (b == 0 || NB1 == 2) {
             v4f v0 = acc[a][i][b][0] * alpha, v1 = acc[a][i][b][1] * alpha;
             if (BIAS) {
@@ -773,8 +821,8 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
               // aux 16 = sc1: write-through, the line is not kept in this XCD's L2.  A tile's 128 KiB of output per CU
               // (4 MiB per XCD = its whole L2) would otherwise evict the A/B panels the next tile streams:
               // measured -5..6 % kernel time at K = 2048-4096 (tools/bench_kernels.py --which ksweep, algos 4 vs 17-19).
-              if (ABL == 4) __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)o, rsD, d_voff + ecol * 2, soff, 0);  // plain (ablation)
-              else __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)o, rsD, d_voff + ecol * 2, soff, 16);
+              if (ABL == 4) __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)o, rsD, dvo + ecol * 2, soff, 0);  // plain (ablation)
+              else __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)o, rsD, dvo + ecol * 2, soff, 16);
               // hipcc (ROCm 7.2) lets the next VALU overwrite the data registers of this 16-byte store (SGPR-offset
               // form) with no wait state: lanes 12-15 of every 16-lane row then stored the NEXT block's unconverted
               // fp32 (seen on MI355X, tools/debug_gemm.py).  Keep the registers live across the required wait states.
@@ -791,7 +839,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
             if (ABL == 1) {
               asm volatile("" ::"v"(o));
             } else {
-              __builtin_amdgcn_raw_buffer_store_b64(o, rsD, d_voff + fq * 8, soff, 16);
+              __builtin_amdgcn_raw_buffer_store_b64(o, rsD, dvo + fq * 8, soff, 16);
               asm volatile("s_nop 1" ::"v"(o) : "memory");
             }
           }
@@ -1012,6 +1060,10 @@ static int launch_p8(const uint8_t* a, const uint8_t* b, uint16_t* D, const floa
     MI_P8_CFG(false, false, 3)
   } else if (algo == 17) {
     MI_P8_CFG(false, false, 4)
+  } else if (algo == 18) {  // timing ablation: block scales staged into LDS but not read (unit scales): wrong results
+    MI_P8_CFG(true, false, 5)
+  } else if (algo == 19) {  // timing ablation: block scales staged and read, MFMAs still get unit scales: wrong results
+    MI_P8_CFG(true, false, 6)
   } else if (mx) {
     if (bias) { MI_P8_CFG(true, true, 0) } else { MI_P8_CFG(true, false, 0) }
   } else {
@@ -1037,7 +1089,7 @@ static int launch_fmt(const void* A, const void* B, void* D, const float* sa_inv
     int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
     hipLaunchKernelGGL((gemm_256_8ph<FA, FB, OUT>), dim3(tiles_m * tiles_n), dim3(512), 0, st, a, b, D, sa_inv, sb_inv,
                        bp, (int)M, (int)N, (int)K, lda, ldb, ldd, tiles_m, tiles_n);
-  } else if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 17) || (algo >= 40 && algo <= 45)) {
+  } else if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 19) || (algo >= 40 && algo <= 45)) {
     return launch_p8<FA, FB>(a, b, (uint16_t*)D, sa_inv, sb_inv, (const uint8_t*)SA, (const uint8_t*)SB, bp, M, N, K, lda, ldb, ldd,
                              algo, mx, st);
   } else if (algo == 13 && !mx) {
@@ -1097,7 +1149,7 @@ static int pick_algo(int algo, int64_t M, int64_t N, int64_t K, int64_t lda, int
   const bool p8_ok = (M % 256 == 0 || M % 192 == 0) && (N % 256 == 0 || N % 192 == 0) && M > 0 && N > 0 && K > 0 &&
                      (K % (2 * BK) == 0) && out == 0 && M * lda < (1LL << 31) && N * ldb < (1LL << 31) &&
                      M * ldd * 2 < (1LL << 31);
-  if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 17) || (algo >= 40 && algo <= 45)) {
+  if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 19) || (algo >= 40 && algo <= 45)) {
     if (!p8_ok) {
       set_error("%s: algo %d needs M,N %% 256 (or 192) == 0, K %% 256 == 0, bf16 output, operands < 2 GiB", who, algo);
       return MI_ERR_SHAPE;
@@ -1139,7 +1191,7 @@ extern "C" int mi_gemm_mxfp8(const void* A, const void* SA, const void* B, const
   if (rc != MI_OK) return rc;
   MI_CHECK_ARG(SA && SB, "mi_gemm_mxfp8: null scale pointer");
   MI_CHECK_ARG(K % 32 == 0, "mi_gemm_mxfp8: K must be a multiple of 32");
-  MI_CHECK_ARG(algo == 0 || algo == 1 || algo == 4 || algo == 5 || (algo >= 40 && algo <= 45), "mi_gemm_mxfp8: algo must be 0, 1, 4, 5 or 40-45");
+  MI_CHECK_ARG(algo == 0 || algo == 1 || algo == 4 || algo == 5 || algo == 18 || algo == 19 || (algo >= 40 && algo <= 45), "mi_gemm_mxfp8: algo must be 0, 1, 4, 5, 18, 19 or 40-45");
   if (M == 0 || N == 0) return MI_OK;
   int a = algo == 0 ? 4 : algo;
   if (a != 1) {

@@ -91,6 +91,18 @@ def main():
                 fns[algo] = (lambda al: (lambda: ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=al)))(algo)
             res = time_interleaved(fns)
             print(f"tiles {m}x{n}x{k}: " + "  ".join(f"algo {al}: {t*1e6:7.1f} us {2.0*m*n*k/t/1e12:6.0f} TF" for al, t in res.items()), flush=True)
+    if "mxab" in args.which:  # interleaved A/B: per-tensor-scaled vs block-scaled GEMM (same persistent kernel, MX adds the scale path)
+        for name, (M, N, K) in SHAPES_3B.items():
+            for kind, (m, n, k) in (("fprop", (M, N, K)), ("dgrad", (M, K, N)), ("wgrad", (N, K, M))):
+                a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
+                sa = torch.randint(120, 131, (k // 32, m), generator=g, device=dev, dtype=torch.uint8)
+                sb = torch.randint(120, 131, (k // 32, n), generator=g, device=dev, dtype=torch.uint8)
+                out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+                res = time_interleaved({"fp8": lambda: ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=4),
+                                        "mx": lambda: ops.gemm_mxfp8(a, sa, b, sb, 0, 0, out=out, algo=4),
+                                        "mx-noread": lambda: ops.gemm_mxfp8(a, sa, b, sb, 0, 0, out=out, algo=18),
+                                        "mx-read-unused": lambda: ops.gemm_mxfp8(a, sa, b, sb, 0, 0, out=out, algo=19)})
+                print(f"mxab {name:4s} {kind:5s} {m}x{n}x{k}: " + "  ".join(f"{al}: {t*1e6:7.1f} us {2.0*m*n*k/t/1e12:6.0f} TF" for al, t in res.items()), flush=True)
     if "mxgemm" in args.which:
         for name, (M, N, K) in SHAPES_3B.items():
             for kind, (m, n, k) in (("fprop", (M, N, K)), ("dgrad", (M, K, N)), ("wgrad", (N, K, M))):

@@ -26,6 +26,20 @@ __global__ __launch_bounds__(512, 2) void k(const v8i* src, float* out, unsigned
           acc[i * 2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[i], b[j], acc[i * 2 + j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
     }
     for (int i = 0; i < 8; ++i) sum += acc[i][0] + acc[i][3];
+  } else if (SHAPE == 17) {  // 16x16x128 with per-lane E8M0 scales in VGPRs (the MXFP8 form)
+    v4f acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = (v4f){0, 0, 0, 0};
+    int sa[4], sb[2];
+    for (int i = 0; i < 4; ++i) sa[i] = 0x7c + ((a[i][0] >> 3) & 7);
+    for (int i = 0; i < 2; ++i) sb[i] = 0x7c + ((b[i][0] >> 5) & 7);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i * 2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[i], b[j], acc[i * 2 + j], 0, 0, 0, sa[i], 0, sb[j]);
+    }
+    for (int i = 0; i < 8; ++i) sum += acc[i][0] + acc[i][3];
   } else {
     v16f acc[2];
     for (int i = 0; i < 2; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0;
@@ -51,13 +65,14 @@ int main() {
   for (int fill = 0; fill < 2; ++fill) {
     for (int i = 0; i < 4096 * 32; ++i) { unsigned char v = rand() & 0xff; if ((v & 0x7f) >= 0x78) v &= 0x3f; h[i] = fill ? 0 : v; }
     hipMemcpy(src, h, 4096 * 32, hipMemcpyHostToDevice);
-    for (int shape : {16, 32}) {
+    for (int shape : {16, 17, 32}) {
       const int iters = 20000;
       hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
       for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
         for (int q = 0; q < 8; ++q) {
           if (shape == 16) hipLaunchKernelGGL(k<16>, 256, 512, 0, 0, src, out, clk, iters);
+          else if (shape == 17) hipLaunchKernelGGL(k<17>, 256, 512, 0, 0, src, out, clk, iters);
           else hipLaunchKernelGGL(k<32>, 256, 512, 0, 0, src, out, clk, iters);
         }
         hipEventRecord(e1); hipEventSynchronize(e1);
