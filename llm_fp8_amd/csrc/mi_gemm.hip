@@ -506,9 +506,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   constexpr int TBM = 2 * (RA0 + RA1), TBN = 4 * (RB0 + RB1);        // workgroup tile
   constexpr int nA1 = MA1 / 2, nB1 = NB1;                            // LDS-DMA pieces per wave of the second halves
   // extra LDS-DMA ops per K-tile at the head of phase 0: the bias window and, for MX, one 256-byte run of block scales per
-  // wave (waves 0-3: k-block w of A for the NEXT step; waves 4-7: k-block w-4 of B for the step AFTER next).  B runs two
-  // steps ahead because its stagers are wave group 1, a phase BEHIND group 0: one step ahead, group 0 read the B scales
-  // before the barrier that follows the stagers' wait -- a race seen as run-to-run differences of the mxfp8 loss.
+  // wave (operand w>>2, k-block w&3) for the NEXT step; phase 3's wait retires them (see MI_WAIT_SYNC).
   constexpr int EX = (MX ? 1 : 0) + (BIAS ? 1 : 0);
   constexpr int W = nA1 + nB1 + 4;                                   // younger ops allowed at the p3 wait (8 for 256x256)
   constexpr int NST = (4 + MA1) * 2;                                 // epilogue stores per wave and tile
@@ -549,15 +547,14 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   // [slot][operand][4 k-blocks][256 rows], the k-block rows 272 B apart: the four 16-lane groups of a scale read (k-blocks
   // 0..3 of rows r..r+15) then fall on disjoint banks; at a 256-B stride they were a 4-way conflict on an LDS that the
   // fragment reads already keep 75 % busy, and the block-scaled GEMM ran 10 % behind the per-tensor one
-  // LDS: A scales [2 slots][4 k-blocks][272] then B scales [3 slots][4][272]
-  constexpr int kSK = 272, kSOp = 4 * kSK, kSB = 2 * kSOp;
+  // LDS: [2 slots][operand A, B][4 k-blocks][272]
+  constexpr int kSK = 272, kSOp = 4 * kSK, kSSlot = 2 * kSOp;
   uint8_t* const sbuf = lds + kLdsBytes;
-  // one op per wave: A scales of (slot_a, K-tile kt_a, rows from row_a) or B scales of (slot_b, kt_b, row_b)
-  auto stage_scales = [&](int slot_a, int kt_a, int row_a, int slot_b, int kt_b, int row_b) {
+  auto stage_scales = [&](int slot, int kt, int row0a, int row0b) {
     if (MX) {
-      const int soff = s_is_b ? (kt_b * 4 + (wave & 3)) * N + row_b : (kt_a * 4 + wave) * M + row_a;
-      uint8_t* dst = s_is_b ? sbuf + kSB + slot_b * kSOp + (wave & 3) * kSK : sbuf + slot_a * kSOp + wave * kSK;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, LDS_PTR(dst), 4, lane * 4, soff, 0, 0);
+      const int soff = (kt * 4 + (wave & 3)) * s_rows + (s_is_b ? row0b : row0a);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, LDS_PTR(sbuf + slot * kSSlot + (wave >> 2) * kSOp + (wave & 3) * kSK), 4,
+                                               lane * 4, soff, 0, 0);
     }
   };
   // bias: every K-tile each wave re-fetches the 256-byte window that starts at its own columns of cursor 1's tile
@@ -644,8 +641,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   uint8_t* const buf1 = lds + kBufBytes;
   // prologue: step 0 complete, (step 1: A0, B0) in flight
   const int kb0 = SK ? sk_k0 * BK : 0;  // first step's K offset (bytes)
-  stage_scales(0, SK ? sk_k0 : 0, ra_0, 0, SK ? sk_k0 : 0, rb_0);  // step 0: A (waves 0-3) and B (waves 4-7)
-  if (MX && s_is_b) stage_scales(0, 0, 0, 1, kt_1, rb_1);          // B scales of step 1 (B is staged two steps ahead)
+  stage_scales(0, SK ? sk_k0 : 0, ra_0, rb_0);
   stage_bias(0, rb_0);
   stage_n<2>(rsA, a0_voff, oa_0 + kb0, buf0 + kOffA0, wave);
   stage_n<2>(rsB, b0_voff, ob_0 + kb0, buf0 + kOffB0, wave);
@@ -667,16 +663,29 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   int as_[4] = {kUnitScale, kUnitScale, kUnitScale, kUnitScale}, b0s[2] = {kUnitScale, kUnitScale}, b1s[2] = {kUnitScale, kUnitScale};
   int as1[4] = {kUnitScale, kUnitScale, kUnitScale, kUnitScale};  // scales of the A1 half (phases 2-3)
   const int sfr = lane & 15, sfq = lane >> 4;
-  int s = 0;      // current step
-  int bslot = 0;  // B-scale slot of the current step (step % 3)
-  // One K-tile = 4 phases.  Waits: phases 0-2 allow W + EX younger LDS-DMA ops, phase 3 allows W; `after_epi`
-  // (uniform): first K-tile behind an epilogue, whose NST stores sit between the awaited loads and the younger ones.
-#define MI_WAIT_SYNC(after_epi, P3)                                    \
-  if (after_epi) wait_vmcnt<W + ((P3) ? 0 : EX) + NST>();              \
-  else wait_vmcnt<W + ((P3) ? 0 : EX)>();                              \
-  __builtin_amdgcn_s_barrier();                                        \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   \
-  __builtin_amdgcn_sched_barrier(0);                                   \
+  int s = 0;  // current step
+  // One K-tile = 4 phases; LDS-DMA issued per phase: p0 {EX, B1(step+1): nB1}, p1 {A1(step+1): nA1}, p2 {A0(step+2): 2},
+  // p3 {B0(step+2): 2}; fragments read at the TOP of a phase (before its wait + barrier): p0 A0/B0, p1 B1, p2 A1.
+  // Wave group 1 runs one barrier behind group 0, so what a phase reads at its top must be known landed at the stagers'
+  // wait TWO phases earlier (one phase earlier would be the barrier group 0 passes only AFTER those reads).  Ops allowed
+  // to stay in flight at the wait of phase p (the wait follows the phase's own issues):
+  //   p0: A1(step) done   -> the 2 + 2 + EX + nB1 younger ones            = W + EX - nA1
+  //   p1: nothing new     -> as loose as p0's successor allows            = W + EX
+  //   p2: A0/B0(step+1)   -> EX + nB1 + nA1 + 2 younger                   = W + EX - 2
+  //   p3: B1(step+1)      -> nA1 + 2 + 2 younger                          = W - nB1
+  // `after_epi` (uniform): first K-tile behind an epilogue, whose NST stores sit between the loads awaited in p0-p2 and the
+  // younger ones.  p3 awaits ops issued AFTER the stores (this K-tile's EX ops and B1), so it is never widened by NST: widened,
+  // it let the next step's block scales / bias window stay in flight past the reads of the following K-tile -- seen as
+  // run-to-run differences of the mxfp8 loss.
+#define MI_WAIT_SYNC(after_epi, PH)                                                                      \
+  {                                                                                                      \
+    constexpr int kAllow = (PH) == 0 ? W + EX - nA1 : (PH) == 1 ? W + EX : (PH) == 2 ? W + EX - 2 : W - nB1; \
+    if ((after_epi) && (PH) != 3) wait_vmcnt<kAllow + NST>(); /* p3 awaits B1 issued AFTER the stores */  \
+    else wait_vmcnt<kAllow>();                                                                           \
+  }                                                                                                      \
+  __builtin_amdgcn_s_barrier();                                                                          \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
+  __builtin_amdgcn_sched_barrier(0);                                                                     \
   __builtin_amdgcn_s_setprio(1);
 #define MI_PIN(NI, NJ, EXPR)                                           \
   _Pragma("unroll") for (int i = 0; i < NI; ++i)                       \
@@ -692,9 +701,8 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
     }
   };
   auto ktile = [&](uint8_t* cur, uint8_t* oth, bool after_epi, int slot) {
-    const uint8_t* sc = sbuf + slot * kSOp + sfq * kSK + sfr;            // A scales: + tile row of the fragment
-    const uint8_t* scb = sbuf + kSB + bslot * kSOp + sfq * kSK + sfr;   // B scales of this step
-    const int bslot2 = bslot == 0 ? 2 : bslot - 1;                      // (bslot + 2) % 3: target of the step after next
+    const uint8_t* sc = sbuf + slot * kSSlot + sfq * kSK + sfr;  // A scales: + tile row of the fragment
+    const uint8_t* scb = sc + kSOp;                              // B scales
     const int sa1 = oa_1 + kt_1 * BK, sb1 = ob_1 + kt_1 * BK;
     const int sa2 = oa_2 + kt_2 * BK, sb2 = ob_2 + kt_2 * BK;
     // ---- phase 0: C[0][*][0][*]
@@ -723,10 +731,10 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
         }
       }
     }
-    stage_scales(slot ^ 1, kt_1, ra_1, bslot2, kt_2, rb_2);
+    stage_scales(slot ^ 1, kt_1, ra_1, rb_1);
     stage_bias(ti_1 & 1, rb_1);
     stage_n<nB1>(rsB, b1_voff, sb1, oth + kOffB1, wave);
-    MI_WAIT_SYNC(after_epi, false)
+    MI_WAIT_SYNC(after_epi, 0)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -737,7 +745,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
 #pragma unroll
     for (int j = 0; j < NB1; ++j) b1f[j] = read_frag(cur + kOffB1, wc * NB1 + j, lane);
     stage_n<nA1>(rsA, a1_voff, sa1, oth + kOffA1, wave);
-    MI_WAIT_SYNC(after_epi, false)
+    MI_WAIT_SYNC(after_epi, 1)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -748,7 +756,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
 #pragma unroll
     for (int i = 0; i < MA1; ++i) af[i] = read_frag(cur + kOffA1, wr * MA1 + i, lane);
     stage_n<2>(rsA, a0_voff, sa2, cur + kOffA0, wave);
-    MI_WAIT_SYNC(after_epi, false)
+    MI_WAIT_SYNC(after_epi, 2)
 #pragma unroll
     for (int i = 0; i < MA1; ++i)
 #pragma unroll
@@ -757,7 +765,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
     MI_PHASE_END();
     // ---- phase 3: C[1][*][0][*]
     stage_n<2>(rsB, b0_voff, sb2, cur + kOffB0, wave);
-    MI_WAIT_SYNC(after_epi, true)
+    MI_WAIT_SYNC(after_epi, 3)
 #pragma unroll
     for (int i = 0; i < MA1; ++i)
 #pragma unroll
@@ -765,7 +773,6 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
     MI_PIN(MA1, 2, acc[1][i][0][j])
     MI_PHASE_END();
     // cursors follow the step
-    bslot = bslot == 2 ? 0 : bslot + 1;
     ++s;
     advance(ti_1, kt_1, oa_1, ob_1, ra_1, rb_1, s + 1);
     advance(ti_2, kt_2, oa_2, ob_2, ra_2, rb_2, s + 2);
