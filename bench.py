@@ -208,8 +208,9 @@ def main():
             torch.cuda.empty_cache()
             out["cpu_baseline"] = cpu_baseline(args.model)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
+    if dist.is_available() and dist.is_initialized():
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 
