@@ -52,8 +52,9 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
   const int c0 = tile_c * 128 + (wave & 1) * 64 + (lane & 7) * 8;
   const float rcp = 1.0f / fp8_max_of<FMT>();
   const bool active = (r0 < rows) && (c0 < cols);
-  float f[8][8];  // values as cast
-  float g[8][8];  // |values| with NaN -> 0, for the block amax (fmaxf semantics)
+  float f[8][8];  // values as cast; a NaN is replaced by 0 here and recorded in `nanmask` (bit 8 i + j): the block amax then
+                  // needs no per-element test (fmaxf semantics: NaN ignored) and the byte is patched to 0x7F after the cast
+  unsigned long long nanmask = 0;
   bool any_nan = false;
   if (PRE == 0) {
     u32 screen = 0;
@@ -150,17 +151,25 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
       }
     }
   }
-  if (__builtin_expect(any_nan, PRE != 0)) {
+  if (__builtin_expect(any_nan, PRE != 0)) {  // PRE == 0: only threads whose packed screen saw a NaN come here
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) g[i][j] = (f[i][j] != f[i][j]) ? 0.0f : fabsf(f[i][j]);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) g[i][j] = fabsf(f[i][j]);
+      for (int j = 0; j < 8; ++j)
+        if (f[i][j] != f[i][j]) {
+          nanmask |= 1ull << (8 * i + j);
+          f[i][j] = 0.0f;
+        }
   }
+  // bytes of a packed fp8 word (elements (i, j0..j0+3)) -> 0x7F where the mask says the source was a NaN (rare path)
+  auto patch4 = [&](u32 w, int bit0) -> u32 {
+    if (__builtin_expect(nanmask != 0, 0)) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if ((nanmask >> (bit0 + k)) & 1) w = (w & ~(0xFFu << (8 * k))) | (0x7Fu << (8 * k));
+    }
+    return w;
+  };
   // NOTE: shuffles below are executed by every lane (inactive lanes carry zeros); rows/cols are
   // multiples of 32 so a 4-lane block group is all-active or all-inactive.
   if (ROWWISE) {
@@ -170,14 +179,14 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
     for (int i = 0; i < 8; ++i) {
       float a = 0.0f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) a = fmaxf(a, g[i][j]);
+      for (int j = 0; j < 8; ++j) a = fmaxf(a, fabsf(f[i][j]));
       a = fmaxf(a, __shfl_xor(a, 1));
       a = fmaxf(a, __shfl_xor(a, 2));
       u32 e = e8m0_roundup(a * rcp);
       float inv = e8m0_inv(e);
       sbytes[i] = e;
-      lo[i] = cvt4_fp8<FMT>(f[i][0] * inv, f[i][1] * inv, f[i][2] * inv, f[i][3] * inv);
-      hi[i] = cvt4_fp8<FMT>(f[i][4] * inv, f[i][5] * inv, f[i][6] * inv, f[i][7] * inv);
+      lo[i] = patch4(cvt4_fp8<FMT>(f[i][0] * inv, f[i][1] * inv, f[i][2] * inv, f[i][3] * inv), 8 * i);
+      hi[i] = patch4(cvt4_fp8<FMT>(f[i][4] * inv, f[i][5] * inv, f[i][6] * inv, f[i][7] * inv), 8 * i + 4);
     }
     if (active) {
       uint8_t* dst = y_row + (int64_t)r0 * cols + c0;
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
     for (int j = 0; j < 8; ++j) {
       float a = 0.0f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) a = fmaxf(a, g[i][j]);
+      for (int i = 0; i < 8; ++i) a = fmaxf(a, fabsf(f[i][j]));
       a = fmaxf(a, __shfl_xor(a, 8));
       a = fmaxf(a, __shfl_xor(a, 16));
       u32 e = e8m0_roundup(a * rcp);
@@ -207,8 +216,8 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
     u32 lo[8], hi[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      lo[i] = cvt4_fp8<FMT>(f[i][0] * inv[0], f[i][1] * inv[1], f[i][2] * inv[2], f[i][3] * inv[3]);
-      hi[i] = cvt4_fp8<FMT>(f[i][4] * inv[4], f[i][5] * inv[5], f[i][6] * inv[6], f[i][7] * inv[7]);
+      lo[i] = patch4(cvt4_fp8<FMT>(f[i][0] * inv[0], f[i][1] * inv[1], f[i][2] * inv[2], f[i][3] * inv[3]), 8 * i);
+      hi[i] = patch4(cvt4_fp8<FMT>(f[i][4] * inv[4], f[i][5] * inv[5], f[i][6] * inv[6], f[i][7] * inv[7]), 8 * i + 4);
     }
     if (active) {
       u32 a[4], b[4], c[4], d[4];
