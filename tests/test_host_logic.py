@@ -64,3 +64,30 @@ def test_llama_config_table():
     assert (c.hidden_size, c.intermediate_size, c.num_hidden_layers) == (4096, 14336, 32) and not c.tie_word_embeddings
     with pytest.raises(KeyError):
         llama.llama_config("gpt-2")
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """The newest committed headline bench line (profiles/r01*_bench_3b_default.json, printed by bench.py on the GPU box)
+    carries every field of the bench contract, incl. the `roofline` and `cpu_baseline` objects."""
+    import glob
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*_bench_3b_default.json")))
+    assert files, "no committed bench line"
+    d = json.load(open(files[-1]))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "tokens/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference")
+    tokens = 16 * 512 * d["n_gpus"]
+    assert abs(d["value"] - tokens / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
