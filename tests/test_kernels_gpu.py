@@ -607,3 +607,44 @@ def test_persistent_gemm_bitwise_reproducible_under_load(ops, dev, mx, shape):
     assert torch.equal(ref, ref_generic) or ((ref.float() - ref_generic.float()).abs() <= 2 ** -6 * ref_generic.float().abs() + 1e-3).all()
     for _ in range(12):
         assert torch.equal(run(), ref)
+
+
+def test_mxfp8_full_size_properties(ops, dev):
+    """fc1-sized activation (8192 x 16384): size-independent properties of the MXFP8 quantiser, checked on the device with
+    torch ops only -- tight power-of-two scales, saturation-free bytes, round-trip error bound, the column-wise copy is the
+    row-wise quantisation of x^T, and the block-scaled GEMM of a BASELINE shape agrees with an fp32 matmul of the dequantised
+    operands."""
+    R, C = 8192, 16384
+    g = torch.Generator(device=dev).manual_seed(21)
+    x = (torch.randn(R, C, device=dev, generator=g) * torch.exp(2 * torch.randn(R, C // 32, device=dev, generator=g)).repeat_interleave(32, 1)).to(torch.bfloat16)
+    y, s, yT, sT = ops.mxfp8_quantize(x, O.E4M3)
+    tab = dequant_table(O.E4M3, dev)
+
+    def check(data, scales, src):  # data [r, c] u8, scales block-major [c/32, r], src [r, c] bf16
+        r, c = src.shape
+        amax = src.float().abs().view(r, c // 32, 32).amax(-1)                     # [r, c/32]
+        e = scales.t().contiguous().to(torch.int32)                                # [r, c/32]
+        pow2 = torch.ldexp(torch.ones_like(amax), e - 127)
+        nz = amax > 0
+        assert (amax[nz] <= 448.0 * pow2[nz]).all()                                # no saturation ...
+        assert (amax[nz] > 224.0 * pow2[nz] * (1 - 2 ** -20)).all()                 # ... and the next smaller power of two would saturate
+        assert ((data & 0x7F) != 0x7F).all()                                        # no NaN byte from finite input
+        deq = tab[data.long()].view(r, c // 32, 32) * pow2[:, :, None]
+        err = (deq - src.float().view(r, c // 32, 32)).abs()
+        assert (err <= 2.0 ** -4 * src.float().abs().view(r, c // 32, 32) + 2.0 ** -10 * pow2[:, :, None]).all()
+
+    check(y, s, x)
+    check(yT, sT, x.t().contiguous())
+    del y, s, yT, sT
+    # block-scaled GEMM at a BASELINE shape vs fp32 matmul of the dequantised operands
+    M, N, K = 8192, 3072, 3072
+    a = (torch.randn(M, K, device=dev, generator=g)).to(torch.bfloat16)
+    b = (torch.randn(N, K, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+    a8, sa, _, _ = ops.mxfp8_quantize(a, O.E4M3, colwise=False)
+    b8, sb, _, _ = ops.mxfp8_quantize(b, O.E4M3, colwise=False)
+    da = tab[a8.long()].view(M, K // 32, 32) * torch.ldexp(torch.ones(M, K // 32, device=dev), sa.t().to(torch.int32) - 127)[:, :, None]
+    db = tab[b8.long()].view(N, K // 32, 32) * torch.ldexp(torch.ones(N, K // 32, device=dev), sb.t().to(torch.int32) - 127)[:, :, None]
+    ref = da.view(M, K) @ db.view(N, K).t()
+    d = ops.gemm_mxfp8(a8, sa, b8, sb)
+    rms = ref.pow(2).mean().sqrt().item()
+    assert ((d.float() - ref).abs() <= 2.0 ** -7 * ref.abs() + 2e-3 * rms).all()
