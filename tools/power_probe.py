@@ -64,3 +64,37 @@ for label in ("random", "zeros"):
         if vals:
             print(f"   {k}: mean {sum(vals) / len(vals):.0f}  min {min(vals)}  max {max(vals)}  (n={len(vals)})")
     print("   smi under load:", json.dumps(smi)[:1200])
+
+# ---- the whole training step (3B, b16 x s512): average board power / clock over ~8 s of steps
+if "--step" in sys.argv:
+    from llm_fp8_amd import train
+    cfg = train.TrainingConfig(model_name="llama-3.2-3b", batch_size=16, max_seq_length=512, mixed_precision="fp8", use_te=True)
+    torch.manual_seed(0)
+    model = train.prepare_model(train.create_model(cfg, dev), cfg)
+    opt, sched = train.create_optimizer(model, cfg)
+    model.train()
+    batch = train.synthetic_batch(cfg, model.config.vocab_size, dev)
+    for _ in range(3):
+        train.train_step(model, batch, opt, sched, cfg)
+    torch.cuda.synchronize()
+    samples, stop = [], False
+
+    def sampler2():
+        while not stop:
+            samples.append(read_hwmon())
+            time.sleep(0.05)
+
+    th = threading.Thread(target=sampler2); th.start()
+    t0 = time.time(); n = 0
+    while time.time() - t0 < 8.0:
+        train.train_step(model, batch, opt, sched, cfg); n += 1
+        if n % 8 == 0:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize(); dt = time.time() - t0
+    stop = True; th.join()
+    print(f"training step: {n / dt * 16 * 512:.0f} tokens/s over {dt:.1f} s ({1e3 * dt / n:.1f} ms/step)")
+    cards = sorted({k.split(':')[0] for s in samples for k in s})
+    best = max(cards, key=lambda c: sum(s.get(c + ':power1_input', 0) for s in samples))
+    pw = [s[best + ':power1_input'] / 1e6 for s in samples if best + ':power1_input' in s]
+    fq = [s[best + ':freq1_input'] / 1e6 for s in samples if best + ':freq1_input' in s]
+    print(f"   {best}: power mean {sum(pw) / len(pw):.0f} W (min {min(pw):.0f}, max {max(pw):.0f}); sclk mean {sum(fq) / len(fq):.0f} MHz (min {min(fq):.0f}, max {max(fq):.0f}); n={len(pw)}")
