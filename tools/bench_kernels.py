@@ -75,7 +75,7 @@ def main():
             for kind, (m, n, k) in (("fprop", (M, N, K)), ("dgrad", (M, K, N)), ("wgrad", (N, K, M))):
                 a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
                 out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
-                fns = {al: (lambda al_: (lambda: ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=al_)))(al) for al in (4, 5, 3)}
+                fns = {al: (lambda al_: (lambda: ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=al_)))(al) for al in ([int(x) for x in os.environ.get('ALGOS', '4,5,3').split(',')])}
                 res = time_interleaved(fns)
                 print(f"algos {name:4s} {kind:5s} {m}x{n}x{k}: " + "  ".join(f"algo {al}: {t*1e6:7.1f} us {2.0*m*n*k/t/1e12:6.0f} TF" for al, t in res.items()), flush=True)
     if "tiles" in args.which:
