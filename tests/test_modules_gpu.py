@@ -526,3 +526,60 @@ def test_decoder_layer_skip_fusion_matches_plain_residual(te, dev, scenario):
     for a, b, name in zip(outs[0], outs[1], ("y", "dx", "dgamma", "dw1")):
         rel = ((a.float() - b.float()).norm() / b.float().norm()).item()
         assert rel < (3e-2 if name == "dgamma" else 1e-2), f"{name}: {rel:.4g}"  # only the rounding of dx + dskip moves (and what it re-quantises to upstream)
+
+
+@pytest.mark.parametrize("scenario", ["default", "hybrid", "mxfp8"])
+def test_fp8_training_curve_tracks_hf_bf16(te, dev, scenario):
+    """The reference validates its FP8 paths by loss curves against bf16 (paper/conference_101719.tex:280-297).  Same seeded
+    4-layer model, same 40 batches, AdamW 1e-3: each scenario's FP8 curve follows the HF bf16 curve (bounded lag, see below)
+    and settles on the same plateau within 3 %."""
+    from transformers.models.llama.modeling_llama import LlamaForCausalLM
+    from llm_fp8_amd import llama, train
+    config = llama.llama_config("llama-3.2-1b", num_hidden_layers=4, hidden_size=512, intermediate_size=1536, num_attention_heads=4,
+                                num_key_value_heads=2, head_dim=128, vocab_size=4096, max_position_embeddings=256, rope_theta=10000.0)
+    torch.manual_seed(11)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        hf = LlamaForCausalLM(config)
+    finally:
+        torch.set_default_dtype(prev)
+    g = torch.Generator().manual_seed(12)
+    # a learnable toy language: next token = (3 * token + 1) mod 61 with 10 % noise, so the curve goes well below ln(V)
+    B, S, steps = 8, 128, 40
+    batches = []
+    for _ in range(steps):
+        x = torch.randint(0, 61, (B, 1), generator=g)
+        seq = [x]
+        for _ in range(S - 1):
+            nxt = (3 * seq[-1] + 1) % 61
+            noise = torch.randint(0, 61, (B, 1), generator=g)
+            seq.append(torch.where(torch.rand(B, 1, generator=g) < 0.1, noise, nxt))
+        batches.append(torch.cat(seq, 1).to(dev))
+
+    def curve(model):
+        model.train()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+        out = []
+        for ids in batches:
+            loss = model(input_ids=ids, labels=ids).loss
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+            opt.step()
+            opt.zero_grad()
+            out.append(float(loss.detach()))
+        return out
+
+    cfg = train.TrainingConfig(model_name="llama-3.2-1b", mixed_precision="fp8", use_te=True, fp8_scenario=scenario)
+    tem = train.prepare_model(llama.TELlamaForCausalLM.from_hf_state_dict(hf.state_dict(), config, scenario).to(dev), cfg)
+    fp8_curve = curve(tem)
+    ref_curve = curve(hf.to(dev))
+    assert ref_curve[-1] < 0.2 * ref_curve[0], ref_curve  # the toy task is learnable (8.4 -> 0.77)
+    # measured: hybrid and mxfp8 follow the bf16 curve step for step (one transient bump of 12 % at step 9); the "ours" recipe
+    # (E4M3 gradients in the MLP) runs up to ~5 steps behind during the steep phase and reaches the same plateau
+    lag = 6 if scenario == "default" else 2
+    for i in range(3, steps):
+        assert fp8_curve[i] <= 1.13 * max(ref_curve[max(0, i - lag):i + 1]), (scenario, i, fp8_curve[i], ref_curve[max(0, i - lag):i + 1])
+        assert fp8_curve[i] >= 0.88 * min(ref_curve[i:i + 2]), (scenario, i, fp8_curve[i], ref_curve[i])
+    tail_fp8, tail_ref = sum(fp8_curve[-10:]) / 10, sum(ref_curve[-10:]) / 10
+    assert abs(tail_fp8 - tail_ref) < 0.03 * tail_ref, (scenario, tail_fp8, tail_ref)
