@@ -189,6 +189,10 @@ int mi_dswiglu_cast(const void* h_bf16, const void* dact_bf16, void* y_fp8, void
  *                     cols % 512 == 0, cols <= 8192.
  */
 int mi_rmsnorm_stats(const void* x_bf16, float* rstd, int64_t rows, int64_t cols, float eps, void* stream);
+/* out = a + b (bf16, one rounding of the fp32 sum) and rstd[r] of the rounded sum in one pass: the residual add of a decoder
+ * layer (te_llama.py:78,81) fused with the statistics pass of the RMSNorm that consumes it. */
+int mi_add_rmsnorm_stats(const void* a_bf16, const void* b_bf16, void* out_bf16, float* rstd, int64_t rows, int64_t cols,
+                         float eps, void* stream);
 int mi_norm_cast(const void* x_bf16, const float* rstd, const void* gamma_bf16, void* y_fp8, void* yT_fp8,
                  const float* scale, float* amax, int64_t rows, int64_t cols, int fmt, void* stream);
 int mi_rmsnorm_bwd(const void* dy_bf16, const void* x_bf16, const float* rstd, const void* gamma_bf16,

@@ -40,6 +40,7 @@ SIGNATURES = {
                             ctypes.c_float, _c_i64, _p],
     "mi_adamw_bf16": [_p, _p, _p, _p, _c_i64, _p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                       ctypes.c_float, _c_i64, _p],
+    "mi_add_rmsnorm_stats": [_p, _p, _p, _p, _c_i64, _c_i64, ctypes.c_float, _p],
     "mi_cast_amax_colsum": [_p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _p],
     "mi_colsum_finish": [_p, _c_i64, _c_i64, _p, _c_int, _p],
     "mi_gemm_workspace_bytes": [],

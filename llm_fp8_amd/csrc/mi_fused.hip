@@ -532,6 +532,50 @@ extern "C" int mi_dswiglu_cast(const void* h_bf16, const void* dact_bf16, void* 
   return mi::launch_swiglu<MI_FMT_E5M2, 1>(h_bf16, dact_bf16, y_fp8, yT_fp8, scale, amax, colsum, rows, F, st);
 }
 
+namespace mi {
+// out = a + b (fp32 sum, one bf16 rounding: what torch's bf16 add yields) and rstd of the ROUNDED sum in the same pass: the
+// residual add of a decoder layer feeds the next RMSNorm, whose statistics pass would re-read `out` from HBM.
+__global__ __launch_bounds__(256) void add_rmsnorm_stats_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
+                                                                uint16_t* __restrict__ out, float* __restrict__ rstd, int rows,
+                                                                int cols, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int64_t off = (int64_t)row * cols;
+  float acc = 0.0f;
+  for (int c = lane * 8; c < cols; c += 512) {
+    const v4i va = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(a + off + c));
+    const v4i vb = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(b + off + c));
+    v4i vo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32 wa = (u32)va[j], wb = (u32)vb[j];
+      const u32 o = pack_bf16x2(__uint_as_float(wa << 16) + __uint_as_float(wb << 16),
+                                __uint_as_float(wa & 0xFFFF0000u) + __uint_as_float(wb & 0xFFFF0000u));
+      const float lo = __uint_as_float(o << 16), hi = __uint_as_float(o & 0xFFFF0000u);
+      acc += lo * lo + hi * hi;
+      vo[j] = (int)o;
+    }
+    *reinterpret_cast<v4i*>(out + off + c) = vo;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) rstd[row] = rsqrtf(acc / (float)cols + eps);
+}
+}  // namespace mi
+
+extern "C" int mi_add_rmsnorm_stats(const void* a_bf16, const void* b_bf16, void* out_bf16, float* rstd, int64_t rows, int64_t cols,
+                                    float eps, void* stream) {
+  MI_CHECK_ARG(a_bf16 && b_bf16 && out_bf16 && rstd, "mi_add_rmsnorm_stats: null pointer");
+  MI_CHECK_ARG(rows >= 0 && cols > 0 && cols % 8 == 0 && rows < (1LL << 31) && cols < (1LL << 31), "mi_add_rmsnorm_stats: bad shape");
+  MI_CHECK_ARG((((uintptr_t)a_bf16 | (uintptr_t)b_bf16 | (uintptr_t)out_bf16) % 16) == 0, "mi_add_rmsnorm_stats: operands must be 16-byte aligned");
+  if (rows == 0) return MI_OK;
+  hipLaunchKernelGGL(mi::add_rmsnorm_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)a_bf16, (const uint16_t*)b_bf16, (uint16_t*)out_bf16, rstd, (int)rows, (int)cols, eps);
+  MI_CHECK_LAUNCH("mi_add_rmsnorm_stats launch");
+  return MI_OK;
+}
+
 extern "C" int mi_rmsnorm_stats(const void* x_bf16, float* rstd, int64_t rows, int64_t cols, float eps, void* stream) {
   MI_CHECK_ARG(x_bf16 && rstd, "mi_rmsnorm_stats: null pointer");
   MI_CHECK_ARG(rows >= 0 && cols > 0 && cols % 8 == 0 && rows < (1LL << 31) && cols < (1LL << 31), "mi_rmsnorm_stats: bad shape");

@@ -23,6 +23,7 @@ import torch
 
 from . import pytorch as te
 from .common.recipe import DelayedScaling, Format, MXFP8BlockScaling
+from .pytorch.module import residual_add_stats
 
 LLAMA_CONFIGS: Dict[str, dict] = {
     "llama-3.2-1b": dict(hidden_size=2048, intermediate_size=8192, num_hidden_layers=16, num_attention_heads=32,
@@ -79,6 +80,14 @@ def _rope_table(dim: int, max_len: int, device) -> torch.Tensor:
     return _ROPE_CACHE[key]
 
 
+def _handed_rstd(h: torch.Tensor):
+    """(rstd, eps) left on the tensor by the previous decoder layer, unless the tensor was modified in place since."""
+    tag = getattr(h, "_mi_rstd", None)
+    if tag is None or tag[2] != h._version:
+        return None
+    return tag[0], tag[1]
+
+
 class TELlamaDecoderLayer(torch.nn.Module):
     """te_llama.py:41-82: MultiheadAttention (+input RMSNorm, GQA, bshd) and LayerNormMLP (RMSNorm, swiglu,
     TE-default bias=True), each under its own fp8_autocast region, residual adds in between."""
@@ -120,14 +129,20 @@ class TELlamaDecoderLayer(torch.nn.Module):
             raise TypeError("attention_mask must be a torch.Tensor")
         fp8 = hidden_states.is_cuda  # FP8 is unconditionally on in the reference layer (te_llama.py:76,79)
         # `_with_skip`: the module hands the residual branch back so that its gradient is added inside the fused
-        # RMSNorm-backward kernel (same values as `h + f(h)`; one elementwise pass less per residual in backward)
+        # RMSNorm-backward kernel (same values as `h + f(h)`; one elementwise pass less per residual in backward).
+        # residual_add_stats: the add also yields the statistics of the RMSNorm that consumes the sum (the next module's, or
+        # -- handed over on the tensor -- the next layer's input norm), saving that norm's own pass over the activations.
         with te.fp8_autocast(enabled=fp8, fp8_recipe=self.attn_recipe):
-            attn_out, skip = self.self_attention(hidden_states, attention_mask=attention_mask,
-                                                 rotary_pos_emb=self.te_rope_emb, _with_skip=True)
-        hidden_states = skip + attn_out
+            attn_out, skip = self.self_attention(hidden_states, attention_mask=attention_mask, rotary_pos_emb=self.te_rope_emb,
+                                                 _with_skip=True, _rstd=_handed_rstd(hidden_states))
+        eps_mlp = self.layernorm_mlp.eps
+        hidden_states, rstd = residual_add_stats(skip, attn_out, eps_mlp)
         with te.fp8_autocast(enabled=fp8, fp8_recipe=self.mlp_recipe):
-            ffn_out, skip = self.layernorm_mlp(hidden_states, _with_skip=True)
-        hidden_states = skip + ffn_out
+            ffn_out, skip = self.layernorm_mlp(hidden_states, _with_skip=True, _rstd=(rstd, eps_mlp))
+        eps_in = self.self_attention.layernorm_qkv.eps  # every decoder layer of a model shares rms_norm_eps
+        hidden_states, rstd = residual_add_stats(skip, ffn_out, eps_in)
+        if rstd is not None:
+            hidden_states._mi_rstd = (rstd, eps_in, hidden_states._version)
         return hidden_states
 
 

@@ -198,12 +198,12 @@ class MultiheadAttention(torch.nn.Module):
                            init_method=output_layer_init_method or init_method)
 
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
-                rotary_pos_emb=None, _with_skip: bool = False, **_ignored):
-        """`_with_skip` (extension): returns (out, skip), see LayerNormLinear.forward."""
+                rotary_pos_emb=None, _with_skip: bool = False, _rstd=None, **_ignored):
+        """`_with_skip` (extension): returns (out, skip); `_rstd`: statistics hand-off, see LayerNormLinear.forward."""
         if _with_skip:
             if not self.input_layernorm:
                 return self._attend(self.qkv(hidden_states), attention_mask, rotary_pos_emb), hidden_states
-            qkv, skip = self.layernorm_qkv(hidden_states, _with_skip=True)
+            qkv, skip = self.layernorm_qkv(hidden_states, _with_skip=True, _rstd=_rstd)
             return self._attend(qkv, attention_mask, rotary_pos_emb), skip
         qkv = self.layernorm_qkv(hidden_states) if self.input_layernorm else self.qkv(hidden_states)
         return self._attend(qkv, attention_mask, rotary_pos_emb)

@@ -37,11 +37,13 @@ def _as_bf16_2d(t: torch.Tensor) -> torch.Tensor:
 class _GemmSpec:
     """Everything non-tensor a GEMM site needs: recipe, meta windows, slot base, update trigger."""
     __slots__ = ("recipe", "meta_fwd", "meta_bwd", "g", "fmt_fwd", "fmt_bwd", "trigger_bwd_update", "training", "eps",
-                 "wcache", "first_mb", "with_skip")
+                 "wcache", "first_mb", "with_skip", "rstd")
 
     def __init__(self, recipe, meta_fwd, meta_bwd, g, trigger_bwd_update, training, eps=1e-5, wcache=None, first_mb=None,
-                 with_skip=False):
+                 with_skip=False, rstd=None):
         self.eps = eps
+        # rstd: RMSNorm statistics of the input already computed by the producer of the input (residual_add_stats)
+        self.rstd = rstd
         # with_skip: the Function also returns its input as a second output (the residual branch); the gradient arriving
         # over it is added inside the RMSNorm-backward kernel instead of by a separate autograd add
         self.with_skip = with_skip
@@ -79,6 +81,28 @@ def _cast_weights(spec: _GemmSpec, g: int, weights, ns, N: int, K: int, dev, nee
     return w8, w8t, siw
 
 
+class _AddStatsFn(torch.autograd.Function):
+    """out = a + b and the RMSNorm statistics of `out` in one pass (mi_add_rmsnorm_stats)."""
+
+    @staticmethod
+    def forward(ctx, a, b, eps):
+        out, rstd = ops.add_rmsnorm_stats(a, b, eps)
+        ctx.mark_non_differentiable(rstd)
+        return out, rstd
+
+    @staticmethod
+    def backward(ctx, dout, _drstd):
+        return dout, dout, None
+
+
+def residual_add_stats(a: torch.Tensor, b: torch.Tensor, eps: float):
+    """`a + b` for the residual stream, plus rstd (or None) for the RMSNorm that consumes the sum: (sum, rstd)."""
+    if (a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.shape == b.shape and a.is_contiguous()
+            and b.is_contiguous() and a.shape[-1] % 8 == 0):
+        return _AddStatsFn.apply(a, b, eps)
+    return a + b, None
+
+
 def _skip_2d(dskip: Optional[torch.Tensor], like: torch.Tensor) -> Optional[torch.Tensor]:
     """Residual-branch gradient as a contiguous bf16 [tokens, features] matrix for mi_rmsnorm_bwd's `dres`."""
     if dskip is None:
@@ -111,7 +135,7 @@ class _FP8LinearFn(torch.autograd.Function):
             wcat = wcat if wcat.dtype == torch.bfloat16 else wcat.to(torch.bfloat16)
             if ln_w is not None:
                 gam = (ln_w if ln_w.dtype == torch.bfloat16 else ln_w.to(torch.bfloat16)).contiguous()
-                rstd = ops.rmsnorm_stats(x2, spec.eps)
+                rstd = spec.rstd if spec.rstd is not None else ops.rmsnorm_stats(x2, spec.eps)
                 x8, xs, xt8, xts = ops.mxfp8_norm_quantize(x2, rstd, gam, spec.fmt_fwd, rowwise=True, colwise=need_wgrad)
                 if need_dgrad:
                     ctx.norm = (x2, rstd, gam, ln_w.dtype)
@@ -132,7 +156,7 @@ class _FP8LinearFn(torch.autograd.Function):
             mf, g = spec.meta_fwd, spec.g
             if ln_w is not None:
                 gam = (ln_w if ln_w.dtype == torch.bfloat16 else ln_w.to(torch.bfloat16)).contiguous()
-                rstd = ops.rmsnorm_stats(x2, spec.eps)
+                rstd = spec.rstd if spec.rstd is not None else ops.rmsnorm_stats(x2, spec.eps)
                 x8, x8t = ops.norm_cast(x2, rstd, gam, mf.scale(3 * g), mf.amax(3 * g), spec.fmt_fwd, want_t=need_wgrad)
                 if need_dgrad:
                     ctx.norm = (x2, rstd, gam, ln_w.dtype)
@@ -226,7 +250,7 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
             return _FP8SwiGLUMLPFn._forward_mx(ctx, x, x2, w1, b1, w2, b2, spec, ln_w, need_dgrad, need_w, bwd)
         if ln_w is not None:  # K9: x is the un-normalised input
             gam = (ln_w if ln_w.dtype == torch.bfloat16 else ln_w.to(torch.bfloat16)).contiguous()
-            rstd = ops.rmsnorm_stats(x2, spec.eps)
+            rstd = spec.rstd if spec.rstd is not None else ops.rmsnorm_stats(x2, spec.eps)
             x8, x8t = ops.norm_cast(x2, rstd, gam, mf.scale(0), mf.amax(0), fmt, want_t=need_w)
             if need_dgrad:
                 ctx.norm = (x2, rstd, gam, ln_w.dtype)
@@ -268,7 +292,7 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
         fmt = spec.fmt_fwd
         if ln_w is not None:
             gam = (ln_w if ln_w.dtype == torch.bfloat16 else ln_w.to(torch.bfloat16)).contiguous()
-            rstd = ops.rmsnorm_stats(x2, spec.eps)
+            rstd = spec.rstd if spec.rstd is not None else ops.rmsnorm_stats(x2, spec.eps)
             x8, xs, xt8, xts = ops.mxfp8_norm_quantize(x2, rstd, gam, fmt, rowwise=True, colwise=need_w)
             if need_dgrad:
                 ctx.norm = (x2, rstd, gam, ln_w.dtype)
@@ -533,15 +557,17 @@ class LayerNormLinear(_FP8Module):
             return _rmsnorm(x, self.layer_norm_weight, self.eps, self.zero_centered_gamma)
         return _layernorm(x, self.layer_norm_weight, self.layer_norm_bias, self.eps, self.zero_centered_gamma)
 
-    def forward(self, inp: torch.Tensor, is_first_microbatch=None, _with_skip: bool = False):
+    def forward(self, inp: torch.Tensor, is_first_microbatch=None, _with_skip: bool = False, _rstd=None):
         """`_with_skip` (extension used by MultiheadAttention / the decoder layer): returns (out, skip) where `skip` carries
-        `inp` for the residual add, its gradient fused into the RMSNorm backward when the fused-norm path is active."""
+        `inp` for the residual add, its gradient fused into the RMSNorm backward when the fused-norm path is active.
+        `_rstd`: (rstd, eps) of `inp` from residual_add_stats, used instead of a statistics pass when eps matches."""
         st = self._prepare(inp.device)
         ws, b = self._weights(), self._bias()
         if st is not None and _can_fuse_norm(self, st[0], inp) and not self.return_layernorm_output:
             recipe, mf, mb, first = st
             return _FP8LinearFn.apply(inp, b, _GemmSpec(recipe, mf, mb, 0, first, self.training, self.eps, self._wcache,
-                                                        is_first_microbatch, with_skip=_with_skip), self.layer_norm_weight, *ws)
+                                                        is_first_microbatch, with_skip=_with_skip, rstd=_usable_rstd(_rstd, inp, self.eps)),
+                                      self.layer_norm_weight, *ws)
         ln = self._norm(inp)
         if st is None:
             w = ws[0] if len(ws) == 1 else torch.cat(ws, 0)
@@ -553,6 +579,16 @@ class LayerNormLinear(_FP8Module):
         if _with_skip:  # unfused route: the residual is the input itself (autograd adds its gradient)
             return out, inp
         return (out, ln) if self.return_layernorm_output else out
+
+
+def _usable_rstd(handoff, inp: torch.Tensor, eps: float):
+    """rstd from a (rstd, eps) hand-off if it belongs to `inp` (row count) and was computed with this module's eps."""
+    if handoff is None:
+        return None
+    rstd, e = handoff
+    if rstd is None or e != eps or rstd.numel() != inp.numel() // inp.shape[-1] or rstd.device != inp.device:
+        return None
+    return rstd
 
 
 def _can_fuse_norm(mod, recipe, inp) -> bool:
@@ -606,13 +642,14 @@ class LayerNormMLP(_FP8Module):
             return _rmsnorm(x, self.layer_norm_weight, self.eps, self.zero_centered_gamma)
         return _layernorm(x, self.layer_norm_weight, self.layer_norm_bias, self.eps, self.zero_centered_gamma)
 
-    def forward(self, inp: torch.Tensor, is_first_microbatch=None, _with_skip: bool = False):
+    def forward(self, inp: torch.Tensor, is_first_microbatch=None, _with_skip: bool = False, _rstd=None):
         st = self._prepare(inp.device)
         if (st is not None and self.activation == "swiglu" and self.fused_swiglu and _can_fuse_norm(self, st[0], inp)):
             recipe, mf, mb, first = st  # K9 + K10: norm -> cast, fc1, SwiGLU -> cast, fc2 in one autograd node
             return _FP8SwiGLUMLPFn.apply(inp, self.fc1_weight, self.fc1_bias, self.fc2_weight, self.fc2_bias,
                                          _GemmSpec(recipe, mf, mb, 0, first, self.training, self.eps, self._wcache,
-                                                   is_first_microbatch, with_skip=_with_skip), self.layer_norm_weight)
+                                                   is_first_microbatch, with_skip=_with_skip, rstd=_usable_rstd(_rstd, inp, self.eps)),
+                                         self.layer_norm_weight)
         out = self._unfused(inp, st, is_first_microbatch)
         return (out, inp) if _with_skip else out  # unfused route: the residual is the input itself
 

@@ -296,6 +296,19 @@ def rmsnorm_stats(x: torch.Tensor, eps: float) -> torch.Tensor:
     return rstd
 
 
+def add_rmsnorm_stats(a: torch.Tensor, b: torch.Tensor, eps: float):
+    """(a + b [same shape, bf16], rstd fp32 [rows]) in one pass; rows = all leading dims, statistics over the last dim."""
+    _dev(a, b)
+    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
+    C = a.shape[-1]
+    R = a.numel() // C
+    out = torch.empty_like(a)
+    rstd = torch.empty(R, dtype=torch.float32, device=a.device)
+    _lib.check(_lib.load().mi_add_rmsnorm_stats(a.data_ptr(), b.data_ptr(), out.data_ptr(), rstd.data_ptr(), R, C, float(eps), _stream()),
+               "mi_add_rmsnorm_stats")
+    return out, rstd
+
+
 def norm_cast(x: torch.Tensor, rstd: torch.Tensor, gamma: torch.Tensor, scale: torch.Tensor, amax: Optional[torch.Tensor],
               fmt: int, want_y: bool = True, want_t: bool = True):
     """K9: (x * rstd[:, None]) * gamma in fp32 -> (y8 [R, C], y8T [C, R]) + amax; no bf16 normalised tensor is written."""

@@ -381,6 +381,21 @@ def test_rope_qkv_split_and_merge_vs_oracle(ops, dev, B, S, nq, nkv, D):
 
 
 # ----------------------------------------------------------------------------------------- K9 RMSNorm -> FP8
+@pytest.mark.parametrize("shape", [(8, 512), (137, 1024), (8192, 3072), (3, 8192), (64, 4104)])
+def test_add_rmsnorm_stats_matches_add_then_stats(ops, dev, shape):
+    """Residual add folded into the statistics pass: the sum is the bf16 add bit for bit, rstd that of the ROUNDED sum."""
+    R, C = shape
+    g = torch.Generator().manual_seed(R * 7 + C)
+    a = (torch.randn(R, C, generator=g) * torch.exp(torch.randn(R, 1, generator=g))).to(torch.bfloat16).to(dev)
+    b = torch.randn(R, C, generator=g).to(torch.bfloat16).to(dev)
+    out, rstd = ops.add_rmsnorm_stats(a, b, 1e-5)
+    want = a + b
+    assert torch.equal(out.view(torch.int16), want.view(torch.int16))
+    _, rstd_ref = O.rmsnorm_f32(bf16_bits(want.cpu()), bf16_bits(torch.ones(C, dtype=torch.bfloat16)), 1e-5)
+    np.testing.assert_allclose(rstd.cpu().numpy(), rstd_ref, rtol=2e-6)
+    np.testing.assert_allclose(rstd.cpu().numpy(), ops.rmsnorm_stats(want, 1e-5).cpu().numpy(), rtol=1e-6)
+
+
 @pytest.mark.parametrize("shape", [(8, 512), (136, 1024), (1024, 3072), (64, 4096)])
 def test_rmsnorm_cast_and_backward_vs_oracle(ops, dev, shape):
     R, C = shape

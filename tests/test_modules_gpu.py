@@ -528,6 +528,51 @@ def test_decoder_layer_skip_fusion_matches_plain_residual(te, dev, scenario):
         assert rel < (3e-2 if name == "dgamma" else 1e-2), f"{name}: {rel:.4g}"  # only the rounding of dx + dskip moves (and what it re-quantises to upstream)
 
 
+def test_residual_stats_handoff_between_decoder_layers(te, dev):
+    """The residual add hands the next norm's rstd over (inside a layer as an argument, across layers on the tensor); a
+    tensor modified in place, or a norm with another eps, ignores the hand-off."""
+    from llm_fp8_amd import llama
+    from llm_fp8_amd.pytorch import ops
+    from llm_fp8_amd.pytorch.module import residual_add_stats, _usable_rstd
+    cfg = llama.llama_config("llama-3.2-1b", num_hidden_layers=1, hidden_size=512, intermediate_size=1024, num_attention_heads=4,
+                             num_key_value_heads=2, head_dim=128, vocab_size=1024, max_position_embeddings=256)
+    torch.manual_seed(9)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device(dev):
+            layer = llama.decoder_layer_cls("default")(cfg, 0)
+    finally:
+        torch.set_default_dtype(prev)
+    layer.to(dev).train()
+    x = torch.randn(2, 128, cfg.hidden_size, device=dev, dtype=torch.bfloat16)
+    with torch.no_grad():
+        h = layer(x)
+        tag = h._mi_rstd
+        assert tag[1] == layer.self_attention.layernorm_qkv.eps and tag[2] == h._version
+        np.testing.assert_allclose(tag[0].cpu().numpy(), ops.rmsnorm_stats(h.view(-1, cfg.hidden_size), tag[1]).cpu().numpy(), rtol=1e-6)
+        assert llama._handed_rstd(h) is not None
+        y_handed = layer(h)
+        h2 = h.clone()                       # same values, no tag: the layer computes the statistics itself
+        assert llama._handed_rstd(h2) is None
+        y_plain = layer(h2)
+        rel = ((y_handed.float() - y_plain.float()).norm() / y_plain.float().norm()).item()
+        assert rel < 2e-3, rel               # rstd differs by summation order only (<= 1 ulp of f32) -> rare FP8 rounding flips
+        h.mul_(2.0)                          # in-place change: stale statistics must not be used
+        assert llama._handed_rstd(h) is None
+    assert _usable_rstd((tag[0], 1e-6), h, 1e-5) is None and _usable_rstd((tag[0][:5], 1e-5), h, 1e-5) is None
+    # autograd: the add distributes the gradient to both branches
+    a = torch.randn(64, 512, device=dev, dtype=torch.bfloat16, requires_grad=True)
+    b = torch.randn(64, 512, device=dev, dtype=torch.bfloat16, requires_grad=True)
+    s, rstd = residual_add_stats(a, b, 1e-5)
+    assert rstd is not None and not rstd.requires_grad
+    w = torch.randn_like(s)
+    (s * w).sum().backward()
+    assert torch.equal(a.grad, w) and torch.equal(b.grad, w)
+    s32, none = residual_add_stats(a.float(), b.float(), 1e-5)  # not bf16: plain add
+    assert none is None and torch.equal(s32, a.float() + b.float())
+
+
 @pytest.mark.parametrize("scenario", ["default", "hybrid", "mxfp8"])
 def test_fp8_training_curve_tracks_hf_bf16(te, dev, scenario):
     """The reference validates its FP8 paths by loss curves against bf16 (paper/conference_101719.tex:280-297).  Same seeded
