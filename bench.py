@@ -116,6 +116,7 @@ def main():
     model = train.prepare_model(train.create_model(cfg, device), cfg)
     vocab = model.config.vocab_size
     n_layers = model.config.num_hidden_layers
+    resolved_mode = train.resolve_sharding_mode(args.sharding_mode, model, device) if dist.is_initialized() else "none"
     model = train.wrap_distributed(model, cfg, device)
     opt, sched = train.create_optimizer(model, cfg)
     model.train()
@@ -168,7 +169,8 @@ def main():
                                      f"fp8_scenario={args.scenario} (te_llama counterpart, lm_head FP8 under the outer recipe), "
                                      "random-init weights, synthetic tokens"),
                        "global_batch": args.batch * world, "seq_len": args.seq,
-                       "parallelism": "single" if world == 1 else f"{'fsdp_full' if args.sharding_mode == 'auto' else args.sharding_mode} dp{world}"},
+                       "parallelism": "single" if resolved_mode == "none" else
+                       f"dp{world} {resolved_mode}" + (" (gradient arena, bucketed RCCL all-reduce)" if resolved_mode == "replicated" else "")},
             "final_loss": loss_val,
         }
         if not args.no_kernel_timing:

@@ -1,0 +1,203 @@
+"""Replicated data parallelism over a flat gradient arena -- the N > 1 path for every model whose whole training state
+(weights + gradients + AdamW moments) fits one MI355X's 288 GB of HBM3E, i.e. all of BASELINE.json's configurations.
+
+The reference wraps the model in FSDP FULL_SHARD whenever more than one GPU is visible (train_multi_gpu.py:137-146,
+:433-445) because its target GPUs cannot hold the replicated state.  On MI355X they can, so nothing has to be sharded:
+the only exchange step of the path is the gradient reduction (SURVEY.md 8e "only where the run actually shards").
+FSDP / DDP stay available through `--sharding_mode fsdp_full | ddp` (train.wrap_distributed).
+
+Layout: one contiguous bf16 (per dtype) arena holds every parameter's gradient, ordered by when backward produces it
+(last module first; q|k|v of one projection adjacent, so the fused wgrad GEMM of `_FP8LinearFn` writes all three in one
+launch -- module._wgrad_out).  The arena is cut into buckets of >= `bucket_mb`; when the last gradient of a bucket has
+been accumulated the bucket is all-reduced (AVG) on RCCL's stream while backward continues: few, large collectives, as
+xGMI's point-to-point links want (7 x ~153 GB/s per GPU, ring collectives are per-link bound).  The optimiser
+(optim.ClippedAdamW) then reads gradients at addresses that never change between steps.
+"""
+from __future__ import annotations
+
+import os
+from contextlib import contextmanager
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+_ALIGN = 64  # elements: slots start on 128-byte boundaries (bf16); sizes that are multiples of it stay gap-free
+
+
+class _Bucket:
+    __slots__ = ("arena", "start", "end", "params", "pending")
+
+    def __init__(self, arena: int, start: int):
+        self.arena, self.start, self.end, self.params, self.pending = arena, start, start, [], 0
+
+
+def _param_groups_in_backward_order(module: torch.nn.Module) -> List[List[torch.nn.Parameter]]:
+    """Direct parameters of each sub-module (registration order inside a module, so query|key|value stay adjacent and in
+    order), modules in reverse pre-order ~ the order in which backward finishes them.  Shared parameters appear once."""
+    seen, groups = set(), []
+    for m in module.modules():
+        g = [p for p in m._parameters.values() if p is not None and p.requires_grad and id(p) not in seen]
+        seen.update(id(p) for p in g)
+        if g:
+            groups.append(g)
+    return groups[::-1]
+
+
+class GradArenaDP(torch.nn.Module):
+    """`module` replicated on every rank of `process_group`; gradients averaged bucket by bucket during backward."""
+
+    def __init__(self, module: torch.nn.Module, process_group=None, bucket_mb: float = 256.0, broadcast: bool = True):
+        super().__init__()
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("GradArenaDP needs an initialised torch.distributed process group")
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        backend = dist.get_backend(process_group)
+        # RCCL averages in the collective; gloo (CPU rehearsal) has no AVG: SUM, then one scaling pass over the arena
+        self._avg_in_collective = backend == "nccl"
+        self._sync = True
+        self._works: list = []
+        self._callback_queued = False
+        self.arenas: List[torch.Tensor] = []
+        self.buckets: List[_Bucket] = []
+        self._bucket_of: Dict[int, _Bucket] = {}
+        self._build(_param_groups_in_backward_order(module), int(bucket_mb * (1 << 20)))
+        if broadcast and self.world > 1:
+            self._broadcast_state()
+
+    # ------------------------------------------------------------------------------------------------ construction
+    def _build(self, groups, bucket_bytes: int):
+        keys: Dict[tuple, int] = {}
+        sizes: List[int] = []
+        plan = []  # (param, arena index, offset)
+        for g in groups:
+            for p in g:
+                key = (p.device, p.dtype)
+                a = keys.setdefault(key, len(keys))
+                if a == len(sizes):
+                    sizes.append(0)
+                plan.append((p, a, sizes[a]))
+                sizes[a] += -(-p.numel() // _ALIGN) * _ALIGN
+        self.arenas = [torch.zeros(max(n, _ALIGN), dtype=dt, device=dev) for (dev, dt), n in zip(keys, sizes)]
+        open_bucket: Dict[int, _Bucket] = {}
+        for p, a, off in plan:
+            arena = self.arenas[a]
+            p._mi_grad_buf = arena[off:off + p.numel()].view(p.shape)
+            p._mi_grad_slot = (arena, off)
+            b = open_bucket.get(a)
+            if b is not None and p.numel() * arena.element_size() >= bucket_bytes:
+                # a parameter that fills a bucket by itself (the embedding table, whose gradient is complete only at the very
+                # end of backward) does not hold back the reduction of what came before it
+                del open_bucket[a]
+                b = None
+            if b is None:
+                b = open_bucket[a] = _Bucket(a, off)
+                self.buckets.append(b)
+            b.params.append(p)
+            b.end = off + -(-p.numel() // _ALIGN) * _ALIGN
+            self._bucket_of[id(p)] = b
+            if (b.end - b.start) * arena.element_size() >= bucket_bytes:
+                del open_bucket[a]
+            p.register_post_accumulate_grad_hook(self._on_grad)
+        for b in self.buckets:
+            b.pending = len(b.params)
+
+    def _broadcast_state(self):
+        """Rank 0's parameters and buffers everywhere (what DDP / FSDP `sync_module_states` do at wrap time)."""
+        with torch.no_grad():
+            for t in list(self.module.parameters()) + list(self.module.buffers()):
+                if t.numel():
+                    dist.broadcast(t.data, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                                   group=self.group)
+
+    # ------------------------------------------------------------------------------------------------ backward side
+    def _on_grad(self, p: torch.nn.Parameter):
+        buf = p._mi_grad_buf
+        g = p.grad
+        if g is not None and g.data_ptr() != buf.data_ptr():
+            # produced outside the arena (embedding, norms, modules that are not ours): move it in and alias
+            buf.copy_(g)
+            p.grad = buf
+        if not self._callback_queued:
+            self._callback_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+        b = self._bucket_of[id(p)]
+        b.pending -= 1
+        if b.pending == 0 and self._sync:
+            self._launch(b)
+
+    def _launch(self, b: _Bucket):
+        if self.world == 1 and not _FORCE_COLLECTIVES:
+            return
+        flat = self.arenas[b.arena][b.start:b.end]
+        op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
+        self._works.append((dist.all_reduce(flat, op=op, group=self.group, async_op=True), flat))
+
+    def _finalize(self):
+        """End of a backward pass (autograd engine callback): reduce what is still open, then make the compute stream wait
+        for the collectives -- stream-side, the host does not block."""
+        try:
+            if self._sync:
+                for b in self.buckets:
+                    if 0 < b.pending < len(b.params):  # same graph on every rank, so every rank closes the same buckets
+                        self._close_partial(b)
+                for w, flat in self._works:
+                    w.wait()
+                    if not self._avg_in_collective:
+                        flat.mul_(1.0 / self.world)
+        finally:
+            self._works.clear()
+            self._callback_queued = False
+            for b in self.buckets:
+                b.pending = len(b.params)
+
+    def _close_partial(self, b: _Bucket):
+        """A bucket some of whose parameters got no gradient in this pass: they contribute zeros on this rank."""
+        if b.pending == 0:
+            return
+        with torch.no_grad():
+            for p in b.params:
+                if p.grad is None:
+                    p._mi_grad_buf.zero_()
+                    p.grad = p._mi_grad_buf
+        b.pending = 0
+        self._launch(b)
+
+    # ------------------------------------------------------------------------------------------------ module surface
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    @contextmanager
+    def no_sync(self):
+        """Gradient accumulation: backward passes inside accumulate into the arena without reducing (DDP.no_sync)."""
+        prev, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = prev
+
+    def describe(self) -> dict:
+        return {"arenas": [{"dtype": str(a.dtype), "bytes": a.numel() * a.element_size()} for a in self.arenas],
+                "buckets": [(b.end - b.start) * self.arenas[b.arena].element_size() for b in self.buckets],
+                "world": self.world}
+
+
+# debug / rehearsal: run the collectives even at world size 1 (exercises the RCCL stream hand-over on a one-GPU box)
+_FORCE_COLLECTIVES = os.environ.get("LLM_FP8_AMD_FORCE_COLLECTIVES") == "1"
+
+
+def replicated_state_bytes(module: torch.nn.Module, moment_bytes: int = 4) -> int:
+    """Weights + gradients + two AdamW moments per trainable parameter (moments counted at fp32 to be safe)."""
+    n = sum(p.numel() * (2 * p.element_size() + 2 * moment_bytes) for p in module.parameters() if p.requires_grad)
+    return n + sum(p.numel() * p.element_size() for p in module.parameters() if not p.requires_grad)
+
+
+def fits_replicated(module: torch.nn.Module, device: torch.device, fraction: float = 0.5) -> bool:
+    """True when the replicated training state takes at most `fraction` of the device's memory (the rest is for
+    activations): 3B -> 39 GB, 8B -> 96 GB of 288 GB."""
+    if device.type != "cuda":
+        return True
+    total = torch.cuda.get_device_properties(device).total_memory
+    return replicated_state_bytes(module) <= fraction * total

@@ -103,6 +103,25 @@ def residual_add_stats(a: torch.Tensor, b: torch.Tensor, eps: float):
     return a + b, None
 
 
+def _wgrad_out(weights, K: int) -> Optional[torch.Tensor]:
+    """Destination of the weight-gradient GEMM inside the data-parallel gradient arena (distributed.GradArenaDP): the
+    [sum N_i, K] block formed by the weights' slots when these are adjacent and in order, the parameters are bf16 and
+    nothing has been accumulated into them yet (gradient accumulation adds into `.grad` instead).  None otherwise."""
+    slot = getattr(weights[0], "_mi_grad_slot", None)
+    if slot is None:
+        return None
+    arena, off = slot
+    if arena.dtype != torch.bfloat16:
+        return None
+    end = off
+    for w in weights:
+        s = getattr(w, "_mi_grad_slot", None)
+        if s is None or s[0] is not arena or s[1] != end or w.grad is not None or w.dtype != torch.bfloat16 or w.shape[1] != K:
+            return None
+        end += w.numel()
+    return arena[off:end].view(-1, K)
+
+
 def _skip_2d(dskip: Optional[torch.Tensor], like: torch.Tensor) -> Optional[torch.Tensor]:
     """Residual-branch gradient as a contiguous bf16 [tokens, features] matrix for mi_rmsnorm_bwd's `dres`."""
     if dskip is None:
@@ -169,6 +188,7 @@ class _FP8LinearFn(torch.autograd.Function):
             ctx.saved_fp8 = (x8t, None, w8t, None, sinv)
         ctx.spec, ctx.ns, ctx.x_shape, ctx.x_dtype = spec, ns, x.shape, x.dtype
         ctx.w_dtypes = [w.dtype for w in weights]
+        ctx.w_refs = weights if need_wgrad else None  # the Parameters themselves (not saved tensors): for _wgrad_out
         ctx.has_bias, ctx.bias_dtype = bias is not None, (None if bias is None else bias.dtype)
         ctx.need_wgrad, ctx.need_dgrad = need_wgrad, need_dgrad
         if spec.with_skip:
@@ -189,7 +209,7 @@ class _FP8LinearFn(torch.autograd.Function):
             if ctx.need_dgrad:
                 dx = ops.gemm_mxfp8(g8, gs, wt8, wts, spec.fmt_bwd, spec.fmt_fwd)
             if ctx.need_wgrad:
-                dw = ops.gemm_mxfp8(gt8, gts, xt8, xts, spec.fmt_bwd, spec.fmt_fwd)
+                dw = ops.gemm_mxfp8(gt8, gts, xt8, xts, spec.fmt_bwd, spec.fmt_fwd, out=_wgrad_out(ctx.w_refs, xt8.shape[0]))
         else:
             mb, g = spec.meta_bwd, spec.g
             if ctx.has_bias:  # the bias gradient rides on the cast of dy
@@ -203,7 +223,7 @@ class _FP8LinearFn(torch.autograd.Function):
             if ctx.need_dgrad:
                 dx = ops.gemm_fp8(g8, wt8, sig, sinv[1], spec.fmt_bwd, spec.fmt_fwd)
             if ctx.need_wgrad:
-                dw = ops.gemm_fp8(g8t, xt8, sig, sinv[0], spec.fmt_bwd, spec.fmt_fwd)
+                dw = ops.gemm_fp8(g8t, xt8, sig, sinv[0], spec.fmt_bwd, spec.fmt_fwd, out=_wgrad_out(ctx.w_refs, xt8.shape[0]))
         db = None
         if ctx.has_bias:
             db = db_fused if db_fused is not None else g2.sum(0, dtype=torch.float32).to(ctx.bias_dtype)
@@ -246,6 +266,7 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
         ctx.spec, ctx.x_shape, ctx.x_dtype = spec, x.shape, x.dtype
         ctx.dtypes = (w1.dtype, None if b1 is None else b1.dtype, w2.dtype, None if b2 is None else b2.dtype)
         ctx.need_dgrad, ctx.need_w = need_dgrad, need_w
+        ctx.w_refs = (w1, w2) if need_w else None  # the Parameters themselves: for _wgrad_out
         if spec.recipe.mxfp8():
             return _FP8SwiGLUMLPFn._forward_mx(ctx, x, x2, w1, b1, w2, b2, spec, ln_w, need_dgrad, need_w, bwd)
         if ln_w is not None:  # K9: x is the un-normalised input
@@ -318,14 +339,14 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
         g2 = _as_bf16_2d(dy)
         g8, gs, gt8, gts = ops.mxfp8_quantize(g2, fmt_b, rowwise=True, colwise=ctx.need_w)
         dact = ops.gemm_mxfp8(g8, gs, w2t8, w2ts, fmt_b, fmt_f)
-        dw2 = ops.gemm_mxfp8(gt8, gts, at8, ats, fmt_b, fmt_f) if ctx.need_w else None
+        dw2 = ops.gemm_mxfp8(gt8, gts, at8, ats, fmt_b, fmt_f, out=_wgrad_out(ctx.w_refs[1:], at8.shape[0])) if ctx.need_w else None
         db2 = g2.sum(0, dtype=torch.float32).to(ctx.dtypes[3]) if ctx.dtypes[3] is not None else None
         want_b1 = ctx.dtypes[1] is not None
         dh8, dhs, dht8, dhts, colsum = ops.mxfp8_dswiglu_quantize(h, dact, fmt_b, rowwise=ctx.need_dgrad, colwise=ctx.need_w,
                                                                   want_colsum=want_b1)
         db1 = ops.colsum_finish(colsum, ctx.dtypes[1]) if want_b1 else None
         dx = ops.gemm_mxfp8(dh8, dhs, w1t8, w1ts, fmt_b, fmt_f) if ctx.need_dgrad else None
-        dw1 = ops.gemm_mxfp8(dht8, dhts, xt8, xts, fmt_b, fmt_f) if ctx.need_w else None
+        dw1 = ops.gemm_mxfp8(dht8, dhts, xt8, xts, fmt_b, fmt_f, out=_wgrad_out(ctx.w_refs[:1], xt8.shape[0])) if ctx.need_w else None
         return dx, dw1, db1, dw2, db2
 
     @staticmethod
@@ -346,14 +367,14 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
             g8, g8t = ops.cast_amax(g2, mb.scale(2), mb.amax(2), fmt_b, want_t=ctx.need_w)
             db2 = None
         dact = ops.gemm_fp8(g8, w2_8t, mb.scale_inv(2), sinv[3], fmt_b, fmt_f)
-        dw2 = ops.gemm_fp8(g8t, a8t, mb.scale_inv(2), sinv[2], fmt_b, fmt_f) if ctx.need_w else None
+        dw2 = ops.gemm_fp8(g8t, a8t, mb.scale_inv(2), sinv[2], fmt_b, fmt_f, out=_wgrad_out(ctx.w_refs[1:], a8t.shape[0])) if ctx.need_w else None
         # dSwiGLU + cast of fc1's grad_output (GEMM index 0: bwd slot 0) + fc1 bias gradient
         want_b1 = ctx.dtypes[1] is not None
         dh8, dh8t, colsum = ops.dswiglu_cast(h, dact, mb.scale(0), mb.amax(0), fmt_b, want_y=ctx.need_dgrad,
                                              want_t=ctx.need_w, want_colsum=want_b1)
         db1 = ops.colsum_finish(colsum, ctx.dtypes[1]) if want_b1 else None
         dx = ops.gemm_fp8(dh8, w1_8t, mb.scale_inv(0), sinv[1], fmt_b, fmt_f) if ctx.need_dgrad else None
-        dw1 = ops.gemm_fp8(dh8t, x8t, mb.scale_inv(0), sinv[0], fmt_b, fmt_f) if ctx.need_w else None
+        dw1 = ops.gemm_fp8(dh8t, x8t, mb.scale_inv(0), sinv[0], fmt_b, fmt_f, out=_wgrad_out(ctx.w_refs[:1], x8t.shape[0])) if ctx.need_w else None
         return _FP8SwiGLUMLPFn._finish_backward(ctx, dx, dw1, db1, dw2, db2, dskip)
 
     @staticmethod

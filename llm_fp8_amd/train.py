@@ -38,7 +38,7 @@ class TrainingConfig:
     num_training_steps: int = 1000
     gradient_accumulation_steps: int = 1
     max_grad_norm: float = 1.0
-    sharding_mode: str = "auto"           # "auto" | "ddp" | "fsdp_full" | "none"
+    sharding_mode: str = "auto"           # "auto" | "replicated" | "ddp" | "fsdp_full" | "none"
     seed: int = 42
     num_hidden_layers: Optional[int] = None  # override for small tests only
     vocab_size: Optional[int] = None
@@ -90,16 +90,32 @@ def prepare_model(model: torch.nn.Module, cfg: TrainingConfig) -> torch.nn.Modul
     return model
 
 
+def resolve_sharding_mode(mode: str, model: torch.nn.Module, device) -> str:
+    """`auto` (DistributedConfig._auto_detect_sharding, train_multi_gpu.py:137-146, picks FSDP FULL_SHARD whenever there is
+    more than one GPU): here the run shards only when it has to -- the replicated state of every BASELINE.json model fits
+    one MI355X (3B: 39 GB, 8B: 96 GB of 288 GB), so `auto` = gradient-arena data parallelism (distributed.GradArenaDP),
+    and FSDP FULL_SHARD only for a model whose replicated state would take more than half of the device.  An explicit
+    ddp / fsdp_full / replicated request is honoured even at world size 1 (rehearsal on a one-GPU box)."""
+    import torch.distributed as dist
+    if mode != "auto":
+        return mode
+    if dist.get_world_size() == 1:
+        return "none"
+    from .distributed import fits_replicated
+    return "replicated" if fits_replicated(model, device) else "fsdp_full"
+
+
 def wrap_distributed(model: torch.nn.Module, cfg: TrainingConfig, device) -> torch.nn.Module:
     """DistributedWrapper (train_multi_gpu.py:328-510)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or cfg.sharding_mode == "none":
         return model
-    mode = cfg.sharding_mode
-    if mode == "auto" and dist.get_world_size() == 1:
-        return model  # an explicit ddp / fsdp_full request is honoured even at world size 1 (rehearsal)
-    if mode == "auto":
-        mode = "fsdp_full"  # DistributedConfig: auto -> FSDP when more than one GPU (train_multi_gpu.py:81-146)
+    mode = resolve_sharding_mode(cfg.sharding_mode, model, device)
+    if mode == "none":
+        return model
+    if mode == "replicated":
+        from .distributed import GradArenaDP
+        return GradArenaDP(model)
     if mode == "ddp":
         from torch.nn.parallel import DistributedDataParallel as DDP
         return DDP(model, device_ids=[device.index] if device.type == "cuda" else None, gradient_as_bucket_view=True)
@@ -169,6 +185,8 @@ def setup_distributed():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if torch.cuda.is_available():
+        if os.environ.get("LLM_FP8_AMD_SHARE_DEVICE") == "1":  # rehearsal: several ranks on the one GPU of a test box
+            local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
     else:
@@ -176,8 +194,15 @@ def setup_distributed():
     if (world > 1 or os.environ.get("LLM_FP8_AMD_FORCE_DIST") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl" if device.type == "cuda" else "gloo", rank=rank, world_size=world,
-                                device_id=device if device.type == "cuda" else None)
+        kw = {}
+        backend = os.environ.get("LLM_FP8_AMD_DIST_BACKEND") or ("nccl" if device.type == "cuda" else "gloo")
+        if backend == "nccl":
+            # RCCL's kernels on a high-priority stream: a bucket's all-reduce gets CUs as the GEMM's workgroups drain
+            # instead of queueing behind the whole backward pass
+            opts = dist.ProcessGroupNCCL.Options()
+            opts.is_high_priority_stream = True
+            kw = {"pg_options": opts, "device_id": device}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, local, world, device
 
 

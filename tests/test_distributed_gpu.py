@@ -12,9 +12,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode,scenario", [("fsdp_full", "default"), ("ddp", "default"), ("fsdp_full", "mxfp8")])
+@pytest.mark.parametrize("mode,scenario", [("fsdp_full", "default"), ("ddp", "default"), ("fsdp_full", "mxfp8"),
+                                           ("replicated", "default"), ("replicated", "mxfp8")])
 def test_train_harness_under_wrappers_world1(dev, mode, scenario):
-    env = dict(os.environ, LLM_FP8_AMD_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # replicated: the gradient-arena wrapper with its RCCL all-reduces forced on at world size 1 (stream hand-over, hooks)
+    env = dict(os.environ, LLM_FP8_AMD_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", LLM_FP8_AMD_FORCE_COLLECTIVES="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29531", "-m", "llm_fp8_amd.train", "--model_name", "llama-3.2-1b", "--num_hidden_layers", "2",
            "--vocab_size", "4096", "--batch_size", "4", "--max_seq_length", "128", "--mixed_precision", "fp8", "--use_te",
@@ -25,3 +27,23 @@ def test_train_harness_under_wrappers_world1(dev, mode, scenario):
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 4 and all(l["loss"] == l["loss"] for l in lines), r.stdout[-2000:]
     assert lines[-1]["loss"] < lines[0]["loss"]
+
+
+@pytest.mark.parametrize("scenario", ["default", "mxfp8"])
+def test_two_ranks_share_the_gpu_gradient_arena(dev, scenario):
+    """Two ranks on the one GPU (gloo transport, CUDA tensors): replicas stay identical through 4 optimiser steps, and the
+    reduced gradient is exactly the bf16 mean of the two ranks' local gradients."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LLM_FP8_AMD_DIST_BACKEND="gloo", LLM_FP8_AMD_SHARE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "tests", "dp_two_rank_worker.py"), scenario]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    outs = sorted((json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")), key=lambda o: o["rank"])
+    assert len(outs) == 2, r.stdout[-2000:]
+    a, b = outs
+    assert a["optimizer"] == b["optimizer"] == "ClippedAdamW" and a["buckets"] >= 3
+    assert a["checksum"] == b["checksum"] and a["absum"] == b["absum"], "replicas diverged"
+    assert a["losses"] != b["losses"]                      # the ranks trained on different data
+    assert all(l == l for l in a["losses"] + b["losses"]) and a["losses"][-1] < a["losses"][0]
+    for o in outs:
+        assert o["worst_grad_err"] == 0.0 and o["aliased"] == o["n_params"] and o["local_differs"] > 0.0, o
