@@ -12,15 +12,24 @@ launch -- module._wgrad_out).  The arena is cut into buckets of >= `bucket_mb`; 
 been accumulated the bucket is all-reduced (AVG) on RCCL's stream while backward continues: few, large collectives, as
 xGMI's point-to-point links want (7 x ~153 GB/s per GPU, ring collectives are per-link bound).  The optimiser
 (optim.ClippedAdamW) then reads gradients at addresses that never change between steps.
+
+Embedding tables are reduced row-sparsely.  An embedding's gradient touches at most batch x seq rows, but it is the LAST
+gradient of backward and (tied to lm_head, or not) the largest parameter: as a dense all-reduce it would be the exposed tail
+of every step (Llama-3.2-3B: 788 MB; over one xGMI link at N = 2 that is ~6 ms).  Instead the embedding's backward only
+hands (token ids, dY rows) to the wrapper; the table's bucket therefore completes as soon as lm_head's wgrad has landed
+(start of backward, fully overlapped), and at the end of backward the ranks all-gather ids + rows (50 MB per rank) and add
+the same deterministic scatter (aten embedding_dense_backward: sort + segmented sum) to their copy of the averaged gradient.
 """
 from __future__ import annotations
 
+import functools
 import os
 from contextlib import contextmanager
 from typing import Dict, List, Optional
 
 import torch
 import torch.distributed as dist
+import torch.nn.functional as F
 
 _ALIGN = 64  # elements: slots start on 128-byte boundaries (bf16); sizes that are multiples of it stay gap-free
 
@@ -44,10 +53,26 @@ def _param_groups_in_backward_order(module: torch.nn.Module) -> List[List[torch.
     return groups[::-1]
 
 
+class _DeferredEmbeddingGrad(torch.autograd.Function):
+    """Embedding lookup whose weight gradient is not produced by autograd: backward leaves (ids, dY) with the wrapper, which
+    reduces them row-sparsely at the end of the pass.  `anchor` is a dummy that requires grad so that backward runs."""
+
+    @staticmethod
+    def forward(ctx, anchor, ids, weight, dp, emb):
+        ctx.dp, ctx.emb, ctx.ids = dp, emb, ids
+        return F.embedding(ids, weight, emb.padding_idx)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ctx.dp._defer_embedding_grad(ctx.emb, ctx.ids, dy)
+        return None, None, None, None, None
+
+
 class GradArenaDP(torch.nn.Module):
     """`module` replicated on every rank of `process_group`; gradients averaged bucket by bucket during backward."""
 
-    def __init__(self, module: torch.nn.Module, process_group=None, bucket_mb: float = 256.0, broadcast: bool = True):
+    def __init__(self, module: torch.nn.Module, process_group=None, bucket_mb: float = 256.0, broadcast: bool = True,
+                 sparse_embedding_grads: bool = True):
         super().__init__()
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("GradArenaDP needs an initialised torch.distributed process group")
@@ -66,6 +91,10 @@ class GradArenaDP(torch.nn.Module):
         self._build(_param_groups_in_backward_order(module), int(bucket_mb * (1 << 20)))
         if broadcast and self.world > 1:
             self._broadcast_state()
+        self._sparse: list = []          # (embedding module, ids, dY) left by this pass' embedding backwards
+        self._anchor = None
+        if sparse_embedding_grads and (self.world > 1 or _FORCE_COLLECTIVES):
+            self._install_sparse_embeddings()
 
     # ------------------------------------------------------------------------------------------------ construction
     def _build(self, groups, bucket_bytes: int):
@@ -112,6 +141,59 @@ class GradArenaDP(torch.nn.Module):
                     dist.broadcast(t.data, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
                                    group=self.group)
 
+    # ------------------------------------------------------------------------------------------------ embeddings
+    def _install_sparse_embeddings(self):
+        for m in self.module.modules():
+            if (type(m) is torch.nn.Embedding and m.weight.requires_grad and id(m.weight) in self._bucket_of
+                    and m.max_norm is None and not m.sparse and not m.scale_grad_by_freq):
+                m.forward = functools.partial(self._embedding_forward, m)  # instance attribute: shadows Embedding.forward
+
+    def _embedding_forward(self, emb, ids):
+        if not (torch.is_grad_enabled() and emb.weight.requires_grad):
+            return F.embedding(ids, emb.weight, emb.padding_idx)
+        if self._anchor is None or self._anchor.device != emb.weight.device:
+            self._anchor = torch.zeros(1, device=emb.weight.device, requires_grad=True)
+        return _DeferredEmbeddingGrad.apply(self._anchor, ids, emb.weight.detach(), self, emb)
+
+    def _defer_embedding_grad(self, emb, ids, dy):
+        self._sparse.append((emb, ids.reshape(-1), dy.reshape(-1, dy.shape[-1])))
+        if not self._callback_queued:
+            self._callback_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+
+    def _reduce_sparse(self):
+        """All ranks: gather every rank's (ids, rows), then the same deterministic scatter into the local copy of the averaged
+        gradient -- identical inputs and a fixed summation order, so the replicas stay bit-identical."""
+        by_emb: Dict[int, list] = {}
+        for emb, ids, dy in self._sparse:
+            by_emb.setdefault(id(emb), [emb, [], []])
+            by_emb[id(emb)][1].append(ids)
+            by_emb[id(emb)][2].append(dy)
+        self._sparse = []
+        with torch.no_grad():
+            for emb, ids_l, dy_l in by_emb.values():
+                p = emb.weight
+                ids = torch.cat(ids_l) if len(ids_l) > 1 else ids_l[0]
+                dy = (torch.cat(dy_l) if len(dy_l) > 1 else dy_l[0]).to(p.dtype).contiguous()
+                if self.world > 1:
+                    ids_all = torch.empty(self.world * ids.numel(), dtype=ids.dtype, device=ids.device)
+                    dy_all = torch.empty((self.world * dy.shape[0], dy.shape[1]), dtype=dy.dtype, device=dy.device)
+                    dist.all_gather_into_tensor(ids_all, ids.contiguous(), group=self.group)
+                    dist.all_gather_into_tensor(dy_all, dy, group=self.group)
+                else:
+                    ids_all, dy_all = ids, dy
+                dense = torch.ops.aten.embedding_dense_backward(dy_all, ids_all, p.shape[0],
+                                                                -1 if emb.padding_idx is None else emb.padding_idx, False)
+                buf = p._mi_grad_buf
+                if p.grad is None:          # untied table: nothing else wrote its slot in this pass
+                    torch.mul(dense, 1.0 / self.world, out=buf)
+                    p.grad = buf
+                else:                       # tied to lm_head: the averaged wgrad is already there
+                    if p.grad.data_ptr() != buf.data_ptr():
+                        buf.copy_(p.grad)
+                        p.grad = buf
+                    buf.add_(dense, alpha=1.0 / self.world)
+
     # ------------------------------------------------------------------------------------------------ backward side
     def _on_grad(self, p: torch.nn.Parameter):
         buf = p._mi_grad_buf
@@ -147,6 +229,8 @@ class GradArenaDP(torch.nn.Module):
                     w.wait()
                     if not self._avg_in_collective:
                         flat.mul_(1.0 / self.world)
+                if self._sparse:
+                    self._reduce_sparse()
         finally:
             self._works.clear()
             self._callback_queued = False

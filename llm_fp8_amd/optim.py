@@ -107,4 +107,6 @@ class ClippedAdamW(torch.optim.Optimizer):
                                          coef_ptr, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
                                          int(self.state[gi[0][1]]["step"]), st)
             _lib.check(rc, "mi_adamw_bf16_multi")
+            # the kernels write through raw addresses: tell autograd (and every cache keyed on `_version`, wcast.py)
+            torch.autograd.graph.increment_version([p for _, p in gi])
         return None

@@ -43,19 +43,41 @@ def main():
     with dp.no_sync():
         dp(**batch).loss.backward()
     local_g = [p.grad.clone() for p in params]
+    table = model.get_input_embeddings().weight
+    # under no_sync the embedding's rows stay deferred with the wrapper: take them as this rank's scatter part and drop them
+    (emb, ids_loc, dy_loc), = dp._sparse
+    dp._sparse.clear()
     for p in params:
         p.grad = None
     restore()
     dp(**batch).loss.backward()
     torch.cuda.synchronize()
-    worst, aliased = 0.0, 0
+    worst, aliased, table_rel = 0.0, 0, None
     for p, lg in zip(params, local_g):
+        aliased += int(p.grad.data_ptr() == p._mi_grad_buf.data_ptr())
         parts = [torch.empty_like(lg) for _ in range(world)]
         dist.all_gather(parts, lg)
         want = (parts[0] + parts[1]) * 0.5  # gloo path: bf16 SUM, then x 1/world (exact)
+        if p is table:
+            # tied table: the lm_head part went through the bucket (exact, as above); the embedding part was reduced
+            # row-sparsely: all-gathered (ids, rows), aten's deterministic scatter over both ranks' tokens, x 1/world
+            ids_g = [torch.empty_like(ids_loc) for _ in range(world)]
+            dy_g = [torch.empty_like(dy_loc.contiguous()) for _ in range(world)]
+            dist.all_gather(ids_g, ids_loc.contiguous())
+            dist.all_gather(dy_g, dy_loc.contiguous())
+            ids_all, dy_all = torch.cat(ids_g), torch.cat(dy_g)
+            same = want.clone().add_(torch.ops.aten.embedding_dense_backward(dy_all, ids_all, table.shape[0], -1, False), alpha=0.5)
+            out["table_bitwise"] = bool(torch.equal(same.view(torch.int16), p.grad.view(torch.int16)))
+            # and against an exact fp64 scatter: aten sums repeated tokens in bf16, so the bound scales with sum |dY_k|
+            exact = torch.zeros(table.shape, dtype=torch.float64, device=table.device).index_add_(0, ids_all, dy_all.double())
+            mag = torch.zeros(table.shape, dtype=torch.float64, device=table.device).index_add_(0, ids_all, dy_all.double().abs())
+            diff = (p.grad.double() - (want.double() + 0.5 * exact)).abs()
+            tol = 2.0 ** -6 * (want.double().abs() + 0.5 * mag) + 1e-9  # (a dropped row would be off by 100 % of its term)
+            table_rel = float((diff / tol).max())
+            out["table_rows_touched"] = int((mag.sum(1) > 0).sum().item())
+            continue
         worst = max(worst, float((p.grad.float() - want.float()).abs().max()))
-        aliased += int(p.grad.data_ptr() == p._mi_grad_buf.data_ptr())
-    out.update(worst_grad_err=worst, aliased=aliased, n_params=len(params), n_arenas=len(saved),
+    out.update(worst_grad_err=worst, aliased=aliased, n_params=len(params), n_arenas=len(saved), table_rel_err=table_rel,
                local_differs=float((local_g[0].float() - params[0].grad.float()).abs().max()))
     for p in params:
         p.grad = None
