@@ -128,6 +128,15 @@ int mi_mxfp8_quantize(const void* x_bf16, void* y_row, void* s_row, void* y_colT
                       int64_t rows, int64_t cols, int fmt, void* stream);
 
 /*
+ * mi_mxfp8_quantize for a tensor that is a ROW-BLOCK of a larger operand (query | key | value weights forming one GEMM
+ * operand, te_llama.py:200-217): y_row / s_colT point at the block's first row inside the larger [R_total, cols] buffers
+ * (contiguous); s_row / y_colT point at the block's first column and use ld_rows (= R_total, >= rows) as their leading
+ * dimension.  colsum (optional): fp32 [ceil(rows/128), cols] partial column sums of x, one row per 128-row tile, for
+ * mi_colsum_finish (bias gradient riding on the quantisation of grad_output).
+ */
+int mi_mxfp8_quantize_ex(const void* x_bf16, void* y_row, void* s_row, void* y_colT, void* s_colT, float* colsum,
+                         int64_t rows, int64_t cols, int64_t ld_rows, int fmt, void* stream);
+/*
  * K7 fused with the GEMM neighbours (MXFP8 counterparts of K9 / K10; same output layout as mi_mxfp8_quantize):
  *   mi_mxfp8_norm_quantize     quantises (x * rstd[r]) * gamma[c]                      (RMSNorm -> MXFP8)
  *   mi_mxfp8_swiglu_quantize   quantises silu(h[:, :F]) * h[:, F:]                     (outputs have F columns)

@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
                                                           const float* __restrict__ aux32, uint8_t* __restrict__ y_row,
                                                           uint8_t* __restrict__ s_row, uint8_t* __restrict__ y_colT,
                                                           uint8_t* __restrict__ s_colT, float* __restrict__ colsum, int rows,
-                                                          int cols, int tiles_c) {
+                                                          int cols, int tiles_c, int ldr) {
+  // ldr: leading dimension of s_row / y_colT (= rows, or the row count of a larger operand this tensor is a row-block of)
   __shared__ float s_col[2][128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile_r = blockIdx.x / tiles_c, tile_c = blockIdx.x % tiles_c;
@@ -128,27 +129,27 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
       }
     }
     any_nan = true;
-    if (PRE == 3 && colsum != nullptr) {
-      float csum[8];
+  }
+  if ((PRE == 3 || PRE == 0) && colsum != nullptr) {  // column sums of the values being quantised (bias gradients)
+    float csum[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float v = 0.0f;
+    for (int j = 0; j < 8; ++j) {
+      float v = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v += f[i][j];
-        v += __shfl_xor(v, 8);
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        csum[j] = v;
-      }
-      if ((lane >> 3) == 0) {
+      for (int i = 0; i < 8; ++i) v += f[i][j];
+      v += __shfl_xor(v, 8);
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      csum[j] = v;
+    }
+    if ((lane >> 3) == 0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s_col[wave >> 1][(wave & 1) * 64 + (lane & 7) * 8 + j] = csum[j];
-      }
-      __syncthreads();
-      if (tid < 128) {
-        const int c = tile_c * 128 + tid;
-        if (c < cols) colsum[(int64_t)tile_r * cols + c] = s_col[0][tid] + s_col[1][tid];
-      }
+      for (int j = 0; j < 8; ++j) s_col[wave >> 1][(wave & 1) * 64 + (lane & 7) * 8 + j] = csum[j];
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int c = tile_c * 128 + tid;
+      if (c < cols) colsum[(int64_t)tile_r * cols + c] = s_col[0][tid] + s_col[1][tid];
     }
   }
   if (__builtin_expect(any_nan, PRE != 0)) {  // PRE == 0: only threads whose packed screen saw a NaN come here
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
       if ((lane & 3) == 0) {  // block-major scales [cols/32, rows]: this lane's 8 rows are 8 contiguous bytes
         const u32 lo4 = sbytes[0] | (sbytes[1] << 8) | (sbytes[2] << 16) | (sbytes[3] << 24);
         const u32 hi4 = sbytes[4] | (sbytes[5] << 8) | (sbytes[6] << 16) | (sbytes[7] << 24);
-        *reinterpret_cast<uint2*>(s_row + (int64_t)(c0 / 32) * rows + r0) = make_uint2(lo4, hi4);
+        *reinterpret_cast<uint2*>(s_row + (int64_t)(c0 / 32) * ldr + r0) = make_uint2(lo4, hi4);
       }
     }
   }
@@ -225,11 +226,11 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
       transpose4x4(lo[4], lo[5], lo[6], lo[7], b[0], b[1], b[2], b[3]);
       transpose4x4(hi[0], hi[1], hi[2], hi[3], c[0], c[1], c[2], c[3]);
       transpose4x4(hi[4], hi[5], hi[6], hi[7], d[0], d[1], d[2], d[3]);
-      uint8_t* dst = y_colT + (int64_t)c0 * rows + r0;
+      uint8_t* dst = y_colT + (int64_t)c0 * ldr + r0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        *reinterpret_cast<uint2*>(dst + (int64_t)j * rows) = make_uint2(a[j], b[j]);
-        *reinterpret_cast<uint2*>(dst + (int64_t)(j + 4) * rows) = make_uint2(c[j], d[j]);
+        *reinterpret_cast<uint2*>(dst + (int64_t)j * ldr) = make_uint2(a[j], b[j]);
+        *reinterpret_cast<uint2*>(dst + (int64_t)(j + 4) * ldr) = make_uint2(c[j], d[j]);
       }
       if (((lane >> 3) & 3) == 0) {  // block-major scales [rows/32, cols]: 8 contiguous bytes for this lane's 8 columns
         const u32 lo4 = sbytes[0] | (sbytes[1] << 8) | (sbytes[2] << 16) | (sbytes[3] << 24);
@@ -242,17 +243,18 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
 
 template <int FMT, int PRE>
 static int launch_mx(const void* x, const void* aux16, const float* aux32, void* y_row, void* s_row, void* y_colT, void* s_colT,
-                     float* colsum, int64_t rows, int64_t cols, hipStream_t st) {
+                     float* colsum, int64_t rows, int64_t cols, hipStream_t st, int64_t ld_rows = 0) {
+  const int ldr = (int)(ld_rows > 0 ? ld_rows : rows);
   const int tiles_r = (int)((rows + 127) / 128), tiles_c = (int)((cols + 127) / 128);
   dim3 grid((unsigned)(tiles_r * tiles_c)), block(256);
   const uint16_t *xp = (const uint16_t*)x, *ap = (const uint16_t*)aux16;
   uint8_t *yr = (uint8_t*)y_row, *sr = (uint8_t*)s_row, *yc = (uint8_t*)y_colT, *sc = (uint8_t*)s_colT;
   if (y_row && y_colT)
-    hipLaunchKernelGGL((mxfp8_quant_kernel<FMT, true, true, PRE>), grid, block, 0, st, xp, ap, aux32, yr, sr, yc, sc, colsum, (int)rows, (int)cols, tiles_c);
+    hipLaunchKernelGGL((mxfp8_quant_kernel<FMT, true, true, PRE>), grid, block, 0, st, xp, ap, aux32, yr, sr, yc, sc, colsum, (int)rows, (int)cols, tiles_c, ldr);
   else if (y_row)
-    hipLaunchKernelGGL((mxfp8_quant_kernel<FMT, true, false, PRE>), grid, block, 0, st, xp, ap, aux32, yr, sr, yc, sc, colsum, (int)rows, (int)cols, tiles_c);
+    hipLaunchKernelGGL((mxfp8_quant_kernel<FMT, true, false, PRE>), grid, block, 0, st, xp, ap, aux32, yr, sr, yc, sc, colsum, (int)rows, (int)cols, tiles_c, ldr);
   else
-    hipLaunchKernelGGL((mxfp8_quant_kernel<FMT, false, true, PRE>), grid, block, 0, st, xp, ap, aux32, yr, sr, yc, sc, colsum, (int)rows, (int)cols, tiles_c);
+    hipLaunchKernelGGL((mxfp8_quant_kernel<FMT, false, true, PRE>), grid, block, 0, st, xp, ap, aux32, yr, sr, yc, sc, colsum, (int)rows, (int)cols, tiles_c, ldr);
   MI_CHECK_LAUNCH("mi_mxfp8_quantize launch");
   return MI_OK;
 }
@@ -283,6 +285,18 @@ extern "C" int mi_mxfp8_quantize(const void* x_bf16, void* y_row, void* s_row, v
   if (rc != MI_OK) return rc;
   if (rows == 0 || cols == 0) return MI_OK;
   return MI_MX_DISPATCH(0, x_bf16, nullptr, nullptr, nullptr, rows, cols);
+}
+
+extern "C" int mi_mxfp8_quantize_ex(const void* x_bf16, void* y_row, void* s_row, void* y_colT, void* s_colT, float* colsum,
+                                    int64_t rows, int64_t cols, int64_t ld_rows, int fmt, void* stream) {
+  int rc = mx_common_check("mi_mxfp8_quantize_ex", x_bf16, y_row, s_row, y_colT, s_colT, rows, cols, fmt);
+  if (rc != MI_OK) return rc;
+  MI_CHECK_ARG(ld_rows >= rows && ld_rows % 8 == 0 && ld_rows < (1LL << 31), "mi_mxfp8_quantize_ex: ld_rows (%lld) must be >= rows and a multiple of 8",
+               (long long)ld_rows);
+  if (rows == 0 || cols == 0) return MI_OK;
+  return (fmt == MI_FMT_E4M3
+              ? mi::launch_mx<MI_FMT_E4M3, 0>(x_bf16, nullptr, nullptr, y_row, s_row, y_colT, s_colT, colsum, rows, cols, (hipStream_t)stream, ld_rows)
+              : mi::launch_mx<MI_FMT_E5M2, 0>(x_bf16, nullptr, nullptr, y_row, s_row, y_colT, s_colT, colsum, rows, cols, (hipStream_t)stream, ld_rows));
 }
 
 extern "C" int mi_mxfp8_norm_quantize(const void* x_bf16, const float* rstd, const void* gamma_bf16, void* y_row, void* s_row,

@@ -81,6 +81,28 @@ def _cast_weights(spec: _GemmSpec, g: int, weights, ns, N: int, K: int, dev, nee
     return w8, w8t, siw
 
 
+def _mx_quantize_weights(weights, ns, N: int, K: int, fmt: int, colwise: bool):
+    """MXFP8 copies of the concatenated weight parts of one GEMM operand (query | key | value): every part is quantised
+    straight into its row-block of the operand's buffers (mi_mxfp8_quantize_ex), no bf16 concatenation."""
+    ws_ = [(w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)).contiguous() for w in weights]
+    if len(ws_) == 1:
+        return ops.mxfp8_quantize(ws_[0], fmt, rowwise=True, colwise=colwise)
+    if any(n % 32 for n in ns):
+        return ops.mxfp8_quantize(torch.cat(ws_, 0), fmt, rowwise=True, colwise=colwise)
+    dev = ws_[0].device
+    w8 = torch.empty((N, K), dtype=torch.uint8, device=dev)
+    sc = torch.empty((K // 32, N), dtype=torch.uint8, device=dev)
+    wt8 = torch.empty((K, N), dtype=torch.uint8, device=dev) if colwise else None
+    sct = torch.empty((N // 32, K), dtype=torch.uint8, device=dev) if colwise else None
+    r = 0
+    for w, n in zip(ws_, ns):
+        ops.mxfp8_quantize(w, fmt, rowwise=True, colwise=colwise,
+                           out=(w8[r:r + n], sc[:, r:r + n], wt8[:, r:r + n] if colwise else None,
+                                sct[r // 32:(r + n) // 32] if colwise else None))
+        r += n
+    return w8, sc, wt8, sct
+
+
 class _AddStatsFn(torch.autograd.Function):
     """out = a + b and the RMSNorm statistics of `out` in one pass (mi_add_rmsnorm_stats)."""
 
@@ -150,8 +172,6 @@ class _FP8LinearFn(torch.autograd.Function):
         bias_bf16 = None if bias is None else bias.to(torch.bfloat16).contiguous()
         ctx.norm = None
         if spec.recipe.mxfp8():
-            wcat = weights[0] if len(weights) == 1 else torch.cat(list(weights), 0)
-            wcat = wcat if wcat.dtype == torch.bfloat16 else wcat.to(torch.bfloat16)
             if ln_w is not None:
                 gam = (ln_w if ln_w.dtype == torch.bfloat16 else ln_w.to(torch.bfloat16)).contiguous()
                 rstd = spec.rstd if spec.rstd is not None else ops.rmsnorm_stats(x2, spec.eps)
@@ -165,8 +185,7 @@ class _FP8LinearFn(torch.autograd.Function):
             if hit is not None and (hit[2] is not None or not need_dgrad):
                 w8, ws, wt8, wts = hit
             else:
-                w8, ws, wt8, wts = ops.mxfp8_quantize(wcat.contiguous(), spec.fmt_fwd, rowwise=True,
-                                                      colwise=need_dgrad or spec.first_mb is True)
+                w8, ws, wt8, wts = _mx_quantize_weights(weights, ns, N, K, spec.fmt_fwd, need_dgrad or spec.first_mb is True)
                 if spec.first_mb is True and spec.wcache is not None:
                     spec.wcache[ck] = (w8, ws, wt8, wts)
             y = ops.gemm_mxfp8(x8, xs, w8, ws, spec.fmt_fwd, spec.fmt_fwd, bias=bias_bf16)
@@ -205,7 +224,12 @@ class _FP8LinearFn(torch.autograd.Function):
         ctx.saved_fp8 = None
         dx = dw = db_fused = None
         if spec.recipe.mxfp8():
-            g8, gs, gt8, gts = ops.mxfp8_quantize(g2, spec.fmt_bwd, rowwise=ctx.need_dgrad, colwise=ctx.need_wgrad)
+            if ctx.has_bias and ctx.bias_dtype in (torch.bfloat16, torch.float32):  # the bias gradient rides on the quantisation
+                g8, gs, gt8, gts, cs = ops.mxfp8_quantize(g2, spec.fmt_bwd, rowwise=ctx.need_dgrad, colwise=ctx.need_wgrad,
+                                                          want_colsum=True)
+                db_fused = ops.colsum_finish(cs, ctx.bias_dtype)
+            else:
+                g8, gs, gt8, gts = ops.mxfp8_quantize(g2, spec.fmt_bwd, rowwise=ctx.need_dgrad, colwise=ctx.need_wgrad)
             if ctx.need_dgrad:
                 dx = ops.gemm_mxfp8(g8, gs, wt8, wts, spec.fmt_bwd, spec.fmt_fwd)
             if ctx.need_wgrad:
@@ -337,10 +361,14 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
         (xt8, xts), (w1t8, w1ts), (at8, ats), (w2t8, w2ts), h, _ = ctx.saved_fp8
         ctx.saved_fp8 = None
         g2 = _as_bf16_2d(dy)
-        g8, gs, gt8, gts = ops.mxfp8_quantize(g2, fmt_b, rowwise=True, colwise=ctx.need_w)
+        if ctx.dtypes[3] is not None:  # fc2 bias gradient rides on the quantisation of dy
+            g8, gs, gt8, gts, cs2 = ops.mxfp8_quantize(g2, fmt_b, rowwise=True, colwise=ctx.need_w, want_colsum=True)
+            db2 = ops.colsum_finish(cs2, ctx.dtypes[3])
+        else:
+            g8, gs, gt8, gts = ops.mxfp8_quantize(g2, fmt_b, rowwise=True, colwise=ctx.need_w)
+            db2 = None
         dact = ops.gemm_mxfp8(g8, gs, w2t8, w2ts, fmt_b, fmt_f)
         dw2 = ops.gemm_mxfp8(gt8, gts, at8, ats, fmt_b, fmt_f, out=_wgrad_out(ctx.w_refs[1:], at8.shape[0])) if ctx.need_w else None
-        db2 = g2.sum(0, dtype=torch.float32).to(ctx.dtypes[3]) if ctx.dtypes[3] is not None else None
         want_b1 = ctx.dtypes[1] is not None
         dh8, dhs, dht8, dhts, colsum = ops.mxfp8_dswiglu_quantize(h, dact, fmt_b, rowwise=ctx.need_dgrad, colwise=ctx.need_w,
                                                                   want_colsum=want_b1)

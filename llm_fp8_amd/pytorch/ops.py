@@ -161,29 +161,51 @@ def gemm_fp8(a8: torch.Tensor, b8: torch.Tensor, sa_inv: torch.Tensor, sb_inv: t
     return out
 
 
-def mxfp8_quantize(x: torch.Tensor, fmt: int = E4M3, rowwise: bool = True, colwise: bool = True):
+def mxfp8_quantize(x: torch.Tensor, fmt: int = E4M3, rowwise: bool = True, colwise: bool = True, out=None,
+                   want_colsum: bool = False):
     """K7.  Returns (y_row [R,C], s_row [C/32,R], y_colT [C,R], s_colT [R/32,C]) (None where not asked); scales are
-    block-major: the E8M0 bytes of one 32-block of every row are contiguous."""
+    block-major: the E8M0 bytes of one 32-block of every row are contiguous.
+    `out`: the same four tensors as row-block views of a larger operand's buffers (rows r.. of [N,C] / columns r.. of
+    [C/32,N] and [C,N] / rows r/32.. of [N/32,C]) -- x is then quantised in place as part of that operand.
+    `want_colsum`: also returns the fp32 partial column sums [ceil(R/128), C] of x (for colsum_finish)."""
     _dev(x)
     assert x.dtype == torch.bfloat16 and x.dim() == 2 and x.is_contiguous()
     R, C = x.shape
     y_row = s_row = y_colT = s_colT = None
-    if rowwise:
-        y_row = torch.empty((R, C), dtype=torch.uint8, device=x.device)
-        s_row = torch.empty((C // 32, R), dtype=torch.uint8, device=x.device)
-    if colwise:
-        y_colT = torch.empty((C, R), dtype=torch.uint8, device=x.device)
-        s_colT = torch.empty((R // 32, C), dtype=torch.uint8, device=x.device)
-    args = (x.data_ptr(), _ptr(y_row), _ptr(s_row), _ptr(y_colT), _ptr(s_colT), R, C, fmt, _stream())
+    ld = R
+    if out is not None:
+        y_row, s_row, y_colT, s_colT = out
+        _dev(y_row, s_row, y_colT, s_colT)
+        assert (y_row is not None) == rowwise and (y_colT is not None) == colwise
+        if rowwise:
+            assert y_row.shape == (R, C) and y_row.is_contiguous() and s_row.shape == (C // 32, R) and s_row.stride(1) == 1
+            ld = s_row.stride(0)
+        if colwise:
+            assert y_colT.shape == (C, R) and y_colT.stride(1) == 1 and s_colT.shape == (R // 32, C) and s_colT.is_contiguous()
+            assert not rowwise or y_colT.stride(0) == ld
+            ld = y_colT.stride(0)
+    else:
+        if rowwise:
+            y_row = torch.empty((R, C), dtype=torch.uint8, device=x.device)
+            s_row = torch.empty((C // 32, R), dtype=torch.uint8, device=x.device)
+        if colwise:
+            y_colT = torch.empty((C, R), dtype=torch.uint8, device=x.device)
+            s_colT = torch.empty((R // 32, C), dtype=torch.uint8, device=x.device)
+    cs = torch.empty(((R + 127) // 128, C), dtype=torch.float32, device=x.device) if want_colsum else None
+    if out is None and not want_colsum:
+        fn, args = _lib.load().mi_mxfp8_quantize, (x.data_ptr(), _ptr(y_row), _ptr(s_row), _ptr(y_colT), _ptr(s_colT), R, C, fmt, _stream())
+    else:
+        fn, args = _lib.load().mi_mxfp8_quantize_ex, (x.data_ptr(), _ptr(y_row), _ptr(s_row), _ptr(y_colT), _ptr(s_colT), _ptr(cs),
+                                                      R, C, ld, fmt, _stream())
     t = KernelTimer.active
     if t is None:
-        rc = _lib.load().mi_mxfp8_quantize(*args)
+        rc = fn(*args)
     else:
         nb = R * C * (2 + (1 + 1 / 32) * (int(rowwise) + int(colwise)))
         with t.span("mxfp8_quantize", f"{R}x{C}", float(R * C), float(nb)):
-            rc = _lib.load().mi_mxfp8_quantize(*args)
+            rc = fn(*args)
     _lib.check(rc, "mi_mxfp8_quantize")
-    return y_row, s_row, y_colT, s_colT
+    return (y_row, s_row, y_colT, s_colT, cs) if want_colsum else (y_row, s_row, y_colT, s_colT)
 
 
 def gemm_mxfp8(a8, sa, b8, sb, fmt_a: int = E4M3, fmt_b: int = E4M3, bias=None, out=None,

@@ -624,6 +624,39 @@ def test_persistent_gemm_bitwise_reproducible_under_load(ops, dev, mx, shape):
         assert torch.equal(run(), ref)
 
 
+@pytest.mark.parametrize("fmt", [O.E4M3, O.E5M2])
+def test_mxfp8_quantize_row_blocks_and_colsum(ops, dev, fmt):
+    """mi_mxfp8_quantize_ex: parts quantised into their row-blocks of a larger operand == quantising the concatenation
+    (all four outputs, bit for bit); and the partial column sums it can emit reduce to the column sums of the input."""
+    g = torch.Generator().manual_seed(31)
+    K = 384
+    parts = [(torch.randn(n, K, generator=g) * s).to(torch.bfloat16).to(dev) for n, s in ((256, 1.0), (64, 30.0), (96, 1e-3))]
+    N = sum(p.shape[0] for p in parts)
+    ref = ops.mxfp8_quantize(torch.cat(parts, 0), fmt)
+    w8 = torch.zeros((N, K), dtype=torch.uint8, device=dev)
+    sc = torch.zeros((K // 32, N), dtype=torch.uint8, device=dev)
+    wt8 = torch.zeros((K, N), dtype=torch.uint8, device=dev)
+    sct = torch.zeros((N // 32, K), dtype=torch.uint8, device=dev)
+    r = 0
+    for p in parts:
+        n = p.shape[0]
+        ops.mxfp8_quantize(p, fmt, out=(w8[r:r + n], sc[:, r:r + n], wt8[:, r:r + n], sct[r // 32:(r + n) // 32]))
+        r += n
+    for got, want in zip((w8, sc, wt8, sct), ref):
+        assert torch.equal(got, want)
+    # row-only / column-only blocks
+    w8b = torch.zeros_like(w8); scb = torch.zeros_like(sc)
+    ops.mxfp8_quantize(parts[1], fmt, rowwise=True, colwise=False, out=(w8b[256:320], scb[:, 256:320], None, None))
+    assert torch.equal(w8b[256:320], ref[0][256:320]) and torch.equal(scb[:, 256:320], ref[1][:, 256:320])
+    x = (torch.randn(392 // 8 * 8 * 4, 160, generator=g) * 3).to(torch.bfloat16).to(dev)  # 1568 rows: ragged last 128-row tile
+    y_row, s_row, y_colT, s_colT, cs = ops.mxfp8_quantize(x, fmt, want_colsum=True)
+    plain = ops.mxfp8_quantize(x, fmt)
+    for got, want in zip((y_row, s_row, y_colT, s_colT), plain):
+        assert torch.equal(got, want)
+    assert cs.shape == ((x.shape[0] + 127) // 128, 160)
+    np.testing.assert_allclose(ops.colsum_finish(cs, torch.float32).cpu().numpy(), x.float().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4)
+
+
 def test_mxfp8_full_size_properties(ops, dev):
     """fc1-sized activation (8192 x 16384): size-independent properties of the MXFP8 quantiser, checked on the device with
     torch ops only -- tight power-of-two scales, saturation-free bytes, round-trip error bound, the column-wise copy is the
