@@ -518,6 +518,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
         }
       }
     }
+    // keep the loop-carried dK / dV accumulators in AGPRs: left to itself the allocator carries them in VGPRs and moves all
+    // 128 registers to AGPRs and back around the MFMAs of every step (302 v_accvgpr moves per step against 32 MFMAs)
+#pragma unroll
+    for (int d = 0; d < DB; ++d) asm volatile("" : "+a"(dka[d]), "+a"(dva[d]));
     if (more) store_step(lds + ((step + 1) & 1) * BUF);
     __syncthreads();
   }
