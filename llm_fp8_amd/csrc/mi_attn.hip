@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
 // heads x 32-row query slices (Q and dO slices staged once for all four waves; row reads for S and dP, transposed reads
 // for the dV^T and dK^T products).
 template <int D, bool CAUSAL>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+__global__ __launch_bounds__(256, D == 128 ? 1 : 2) void attn_bwd_dkdv_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                                const uint16_t* __restrict__ v, const uint16_t* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                uint16_t* __restrict__ dk, uint16_t* __restrict__ dv, int S, int H,
@@ -520,8 +520,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
     }
     // keep the loop-carried dK / dV accumulators in AGPRs: left to itself the allocator carries them in VGPRs and moves all
     // 128 registers to AGPRs and back around the MFMAs of every step (302 v_accvgpr moves per step against 32 MFMAs)
+    // (head_dim 64 is bounded to 2 waves per SIMD = 256 registers, where the compiler uses the VGPR form of the MFMAs and
+    // needs no AGPRs at all; with a bound of 1 it assumes AGPRs may be needed, selects the AGPR form and copies around it)
+    if (D == 128) {
 #pragma unroll
-    for (int d = 0; d < DB; ++d) asm volatile("" : "+a"(dka[d]), "+a"(dva[d]));
+      for (int d = 0; d < DB; ++d) asm volatile("" : "+a"(dka[d]), "+a"(dva[d]));
+    }
     if (more) store_step(lds + ((step + 1) & 1) * BUF);
     __syncthreads();
   }
