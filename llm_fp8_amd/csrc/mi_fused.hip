@@ -318,38 +318,53 @@ __global__ __launch_bounds__(256) void norm_cast_kernel(const uint16_t* __restri
 // RMSNorm backward.  dy = grad w.r.t. the normalised output (the dgrad GEMM's bf16 result), xhat = x * rstd:
 //   dx[r,c]  = rstd[r] * (dy*g - xhat * mean_c(dy*g*xhat))          (+ dres[r,c] if a residual gradient is given)
 //   dgp[b,c] = sum over block b's rows of dy * xhat                  (fp32 partials, fixed order; caller adds the blocks)
-// One wave per row per pass (the row lives in registers: cols <= 8192), 4 waves per block, ROWS_PER_WAVE rows per wave.
+// WPR waves share a row (each keeps its cols / WPR slice of the row in registers between the two passes and exchanges its part
+// of the row's dot product through LDS: one barrier per row group); 4 / WPR rows are in flight per block.  With one wave per
+// row, hidden 3072 needs 236 VGPRs (2 waves per SIMD) and hidden 4096 spills into AGPRs at 1 wave per SIMD -- too little
+// memory-level parallelism for a streaming kernel; two waves per row halve gamma, the dgamma accumulators and the row copy.
 constexpr int kNormMaxVec = 16;  // 16 x 8 x 64 = 8192 columns
-template <int NVEC>
+template <int NVEC, int WPR>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
                                                           const float* __restrict__ rstd, const uint16_t* __restrict__ gamma,
                                                           const uint16_t* __restrict__ dres, uint16_t* __restrict__ dx,
                                                           float* __restrict__ dgp, int rows, int rows_per_block) {
-  extern __shared__ float s_dg[];  // [4][cols]
+  static_assert(NVEC % WPR == 0 && (WPR == 1 || WPR == 2 || WPR == 4), "row split");
+  extern __shared__ float s_dg[];  // [4 / WPR][cols]
+  __shared__ float s_dot[2][4];    // [parity][wave]: per-wave parts of the dot products of the rows in flight
   constexpr int cols = NVEC * 512;  // 512 columns per wave-wide vector step
+  constexpr int NV = NVEC / WPR, R = 4 / WPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  v4i gq[NVEC];          // gamma, packed bf16
-  float dgacc[NVEC][8];  // this wave's share of dgamma
+  const int slot = wave / WPR, part = wave % WPR;
+  const int col0 = part * NV * 512 + lane * 8;
+  v4i gq[NV];          // gamma, packed bf16
+  float dgacc[NV][8];  // this wave's share of dgamma
 #pragma unroll
-  for (int v = 0; v < NVEC; ++v) {
-    gq[v] = *reinterpret_cast<const v4i*>(gamma + v * 512 + lane * 8);
+  for (int v = 0; v < NV; ++v) {
+    gq[v] = *reinterpret_cast<const v4i*>(gamma + col0 + v * 512);
 #pragma unroll
     for (int j = 0; j < 8; ++j) dgacc[v][j] = 0.0f;
   }
   const int row_begin = blockIdx.x * rows_per_block;
   const int row_end = min(rows, row_begin + rows_per_block);
-  for (int row = row_begin + wave; row < row_end; row += 4) {
-    const float rs = rstd[row];
-    v4i dq[NVEC], xq[NVEC];
+  const int iters = (row_end - row_begin + R - 1) / R;  // the same for every wave of the block: the loop holds a barrier
+  for (int it = 0; it < iters; ++it) {
+    const int row = row_begin + it * R + slot;
+    const bool valid = row < row_end;
+    const float rs = valid ? rstd[row] : 0.0f;
+    v4i dq[NV], xq[NV];
     float dot = 0.0f;
 #pragma unroll
-    for (int v = 0; v < NVEC; ++v) {
-      const int64_t off = (int64_t)row * cols + v * 512 + lane * 8;
-      dq[v] = *reinterpret_cast<const v4i*>(dy + off);
-      xq[v] = *reinterpret_cast<const v4i*>(x + off);
+    for (int v = 0; v < NV; ++v) {
+      dq[v] = (v4i){0, 0, 0, 0};
+      xq[v] = (v4i){0, 0, 0, 0};
+      if (valid) {
+        const int64_t off = (int64_t)row * cols + col0 + v * 512;
+        dq[v] = *reinterpret_cast<const v4i*>(dy + off);
+        xq[v] = *reinterpret_cast<const v4i*>(x + off);
+      }
     }
 #pragma unroll
-    for (int v = 0; v < NVEC; ++v)
+    for (int v = 0; v < NV; ++v)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float d0 = __uint_as_float((u32)dq[v][j] << 16), d1 = __uint_as_float((u32)dq[v][j] & 0xFFFF0000u);
@@ -361,36 +376,49 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const uint16_t* __rest
       }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) dot += __shfl_xor(dot, o);
+    if (WPR > 1) {
+      if (lane == 0) s_dot[it & 1][wave] = dot;
+      __syncthreads();
+      dot = s_dot[it & 1][slot * WPR];
+#pragma unroll
+      for (int q = 1; q < WPR; ++q) dot += s_dot[it & 1][slot * WPR + q];  // fixed order: every wave of the row gets the same sum
+    }
     const float c = dot / (float)cols;
+    if (valid) {
 #pragma unroll
-    for (int v = 0; v < NVEC; ++v) {
-      const int64_t off = (int64_t)row * cols + v * 512 + lane * 8;
-      v4i rv = {0, 0, 0, 0};
-      if (dres) rv = *reinterpret_cast<const v4i*>(dres + off);
-      v4i ov;
+      for (int v = 0; v < NV; ++v) {
+        const int64_t off = (int64_t)row * cols + col0 + v * 512;
+        v4i rv = {0, 0, 0, 0};
+        if (dres) rv = *reinterpret_cast<const v4i*>(dres + off);
+        v4i ov;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float d0 = __uint_as_float((u32)dq[v][j] << 16), d1 = __uint_as_float((u32)dq[v][j] & 0xFFFF0000u);
-        const float x0 = __uint_as_float((u32)xq[v][j] << 16) * rs, x1 = __uint_as_float((u32)xq[v][j] & 0xFFFF0000u) * rs;
-        const float g0 = __uint_as_float((u32)gq[v][j] << 16), g1 = __uint_as_float((u32)gq[v][j] & 0xFFFF0000u);
-        float o0 = rs * (d0 * g0 - x0 * c), o1 = rs * (d1 * g1 - x1 * c);
-        if (dres) {
-          o0 += __uint_as_float((u32)rv[j] << 16);
-          o1 += __uint_as_float((u32)rv[j] & 0xFFFF0000u);
+        for (int j = 0; j < 4; ++j) {
+          const float d0 = __uint_as_float((u32)dq[v][j] << 16), d1 = __uint_as_float((u32)dq[v][j] & 0xFFFF0000u);
+          const float x0 = __uint_as_float((u32)xq[v][j] << 16) * rs, x1 = __uint_as_float((u32)xq[v][j] & 0xFFFF0000u) * rs;
+          const float g0 = __uint_as_float((u32)gq[v][j] << 16), g1 = __uint_as_float((u32)gq[v][j] & 0xFFFF0000u);
+          float o0 = rs * (d0 * g0 - x0 * c), o1 = rs * (d1 * g1 - x1 * c);
+          if (dres) {
+            o0 += __uint_as_float((u32)rv[j] << 16);
+            o1 += __uint_as_float((u32)rv[j] & 0xFFFF0000u);
+          }
+          ov[j] = (int)pack_bf16x2(o0, o1);
         }
-        ov[j] = (int)pack_bf16x2(o0, o1);
+        *reinterpret_cast<v4i*>(dx + off) = ov;
       }
-      *reinterpret_cast<v4i*>(dx + off) = ov;
     }
   }
-  // block-level dgamma partial: 4 waves -> LDS -> one row of dgp (fixed order)
+  // block-level dgamma partial: the R row slots -> LDS -> one row of dgp (fixed order)
 #pragma unroll
-  for (int v = 0; v < NVEC; ++v)
+  for (int v = 0; v < NV; ++v)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s_dg[wave * cols + v * 512 + lane * 8 + j] = dgacc[v][j];
+    for (int j = 0; j < 8; ++j) s_dg[slot * cols + col0 + v * 512 + j] = dgacc[v][j];
   __syncthreads();
-  for (int c = threadIdx.x; c < cols; c += 256)
-    dgp[(int64_t)blockIdx.x * cols + c] = (s_dg[c] + s_dg[cols + c]) + (s_dg[2 * cols + c] + s_dg[3 * cols + c]);
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    float a = s_dg[c];
+#pragma unroll
+    for (int q = 1; q < R; ++q) a += s_dg[q * cols + c];
+    dgp[(int64_t)blockIdx.x * cols + c] = a;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ cross-entropy
@@ -626,14 +654,15 @@ extern "C" int mi_rmsnorm_bwd(const void* dy_bf16, const void* x_bf16, const flo
   const int rows_per_block = (int)((rows + n_partials - 1) / n_partials);
   const int rpb = rows_per_block < 1 ? 1 : rows_per_block;
   const size_t shm = (size_t)(4 * cols * sizeof(float));
-#define MI_RB(NV)                                                                                                         \
+#define MI_RB(NV, WPRv)                                                                                                   \
   case NV:                                                                                                                \
-    hipLaunchKernelGGL(mi::rmsnorm_bwd_kernel<NV>, dim3(n_partials), dim3(256), shm, (hipStream_t)stream,                 \
+    hipLaunchKernelGGL((mi::rmsnorm_bwd_kernel<NV, WPRv>), dim3(n_partials), dim3(256), shm, (hipStream_t)stream,         \
                        (const uint16_t*)dy_bf16, (const uint16_t*)x_bf16, rstd, (const uint16_t*)gamma_bf16,              \
                        (const uint16_t*)dres_bf16, (uint16_t*)dx_bf16, dgamma_partial, (int)rows, rpb);                   \
     break;
   switch ((int)(cols / 512)) {
-    MI_RB(1) MI_RB(2) MI_RB(3) MI_RB(4) MI_RB(5) MI_RB(6) MI_RB(7) MI_RB(8) MI_RB(10) MI_RB(12) MI_RB(14) MI_RB(16)
+    MI_RB(1, 1) MI_RB(2, 1) MI_RB(3, 1) MI_RB(4, 2) MI_RB(5, 1) MI_RB(6, 2) MI_RB(7, 1) MI_RB(8, 2) MI_RB(10, 2) MI_RB(12, 4)
+    MI_RB(14, 2) MI_RB(16, 4)
     default:
       mi::set_error("mi_rmsnorm_bwd: unsupported width %lld (cols/512 must be 1-8, 10, 12, 14 or 16)", (long long)cols);
       return MI_ERR_SHAPE;
