@@ -50,3 +50,22 @@ def test_two_ranks_share_the_gpu_gradient_arena(dev, scenario):
         # the tied embedding table: bucket part exact; row-sparse part = aten's deterministic scatter of the all-gathered rows
         # (bitwise), and within bf16 summation error of an exact fp64 scatter
         assert o["table_bitwise"] and o["table_rel_err"] <= 1.0 and o["table_rows_touched"] > 100, o
+
+
+def test_bench_two_rank_path_on_one_gpu(dev):
+    """bench.py launched the way the driver launches it for N = 2 (torch.distributed.run, one JSON line from rank 0), with the
+    two ranks sharing the box's GPU over gloo: the N > 1 code path of the bench itself (barriers, max-over-ranks time, the
+    resolved parallelism mode), on a 2-layer model."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LLM_FP8_AMD_DIST_BACKEND="gloo", LLM_FP8_AMD_SHARE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29535", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--layers", "2",
+           "--batch", "4", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 8
+    assert out["config"]["parallelism"].startswith("dp2 replicated")
+    assert out["value"] > 0 and abs(out["value"] - 8 * 512 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    assert out["final_loss"] == out["final_loss"] and "roofline" in out and "cpu_baseline" not in out
