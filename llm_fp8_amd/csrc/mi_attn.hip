@@ -5,8 +5,9 @@
 //                     the B operand of  S^T = K . Q^T  (v_mfma_f32_32x32x16_bf16), so a lane holds 2 x 16 scores of ONE
 //                     query row: the online-softmax state (m, l) and the rescale of O^T are lane-local.  The S^T
 //                     accumulators, converted pairwise to bf16, are directly the B operand of  O^T += V^T . P^T ; the
-//                     V^T fragments come from the row-major V tile with ds_read_b64_tr_b16.  K/V tiles of 64 keys are
-//                     register-staged into a double-buffered, XOR-swizzled LDS image; one barrier per tile.
+//                     V^T fragments come from the row-major V tile with ds_read_b64_tr_b16.  K/V tiles of 64 keys go
+//                     global -> LDS by DMA (buffer_load ... lds; the XOR swizzle of the image is applied on the global
+//                     side) into a double buffer; one barrier per tile; operand fragments are read one k-step ahead.
 //   attn_bwd_dq_kernel / attn_bwd_dkdv_kernel   recompute P from the stored log-sum-exp (no S x S tensor); dQ and
 //                     dK/dV are separate passes so that no sum crosses workgroups (bitwise reproducible, no atomics).
 //
@@ -76,22 +77,30 @@ __device__ __forceinline__ void retire(float& f) { asm volatile("" : "+v"(f)); }
 constexpr int ATT_QB = 128;  // query rows per workgroup (4 waves x 32)
 constexpr int ATT_KB = 64;   // keys per tile
 
+// LDS-DMA staging (buffer_load_dwordx4 ... lds): a wave-wide instruction deposits 64 x 16 bytes at consecutive LDS addresses,
+// so the tile image's XOR swizzle is applied on the GLOBAL side: lane l of this wave's i-th instruction fetches the chunk
+// (row, ch) whose image slot is byte (4 i + w) 1024 + 16 l.  No staging registers, no ds_write, no VALU address math per tile
+// (per-lane voffset fixed for the kernel, tile advance in the scalar offset).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+#define MI_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 template <int D>
-__device__ __forceinline__ void stage_load(v4i (&reg)[D / 32], const uint16_t* base, int64_t tok_stride, int tid) {
+__device__ __forceinline__ void dma_voffsets(int* voff, int64_t tok_stride, int tid) {
+  const int lane = tid & 63, w = tid >> 6;
 #pragma unroll
   for (int i = 0; i < D / 32; ++i) {
-    const int c = tid + 256 * i, row = c / (D / 8), ch = c % (D / 8);
-    reg[i] = *reinterpret_cast<const v4i*>(base + (int64_t)row * tok_stride + ch * 8);
+    const int p = (4 * i + w) * 1024 + 16 * lane;
+    const int row = p / (2 * D), slot = (p % (2 * D)) / 16;
+    const int ch = D == 128 ? slot ^ (((row & 3) << 2) | ((row >> 2) & 3)) : slot ^ (((row & 1) << 2) | ((row >> 1) & 3));
+    voff[i] = (int)((int64_t)row * tok_stride * 2) + 16 * ch;
   }
 }
 template <int D>
-__device__ __forceinline__ void stage_store(const v4i (&reg)[D / 32], char* tile, int tid) {
+__device__ __forceinline__ void stage_dma(rsrc_t rs, const int* voff, int soff, char* tile, int w) {
 #pragma unroll
-  for (int i = 0; i < D / 32; ++i) {
-    const int c = tid + 256 * i, row = c / (D / 8), ch = c % (D / 8);
-    *reinterpret_cast<v4i*>(tile + tile_off<D>(row, ch)) = reg[i];
-  }
+  for (int i = 0; i < D / 32; ++i)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, MI_LDS_PTR(tile + (4 * i + w) * 1024), 16, voff[i], soff, 0, 0);
 }
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <int D, bool CAUSAL, bool DIAG = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
@@ -127,11 +136,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
     for (int i = 0; i < 16; ++i) oacc[d][i] = 0.0f;
   float m = -1.0e30f, l = 0.0f;
 
-  v4i kreg[D / 32], vreg[D / 32];
-  stage_load<D>(kreg, kbase, k_ts, tid);
-  stage_load<D>(vreg, vbase, v_ts, tid);
-  stage_store<D>(kreg, lds, tid);
-  stage_store<D>(vreg, lds + 2 * TILE, tid);
+  // K / V tiles of 64 keys go global -> LDS by DMA, double-buffered: tile j + 1 is requested at the top of tile j
+  const rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (int)((((int64_t)S - 1) * k_ts + D) * 2), 0x00020000);
+  const rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (int)((((int64_t)S - 1) * v_ts + D) * 2), 0x00020000);
+  int kvo[D / 32], vvo[D / 32];
+  dma_voffsets<D>(kvo, k_ts, tid);
+  dma_voffsets<D>(vvo, v_ts, tid);
+  stage_dma<D>(rsK, kvo, 0, lds, w);
+  stage_dma<D>(rsV, vvo, 0, lds + 2 * TILE, w);
+  dma_wait_all();
   __syncthreads();
 
   unsigned long long tsum[5] = {0, 0, 0, 0, 0}, t_prev = 0;
@@ -150,8 +163,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
     const char* vt = lds + (2 + (j & 1)) * TILE;
     const bool more = j + 1 < ntiles;
     if (more) {
-      stage_load<D>(kreg, kbase + (int64_t)(j + 1) * ATT_KB * k_ts, k_ts, tid);
-      stage_load<D>(vreg, vbase + (int64_t)(j + 1) * ATT_KB * v_ts, v_ts, tid);
+      stage_dma<D>(rsK, kvo, (int)((int64_t)(j + 1) * ATT_KB * k_ts * 2), lds + ((j + 1) & 1) * TILE, w);
+      stage_dma<D>(rsV, vvo, (int)((int64_t)(j + 1) * ATT_KB * v_ts * 2), lds + (2 + ((j + 1) & 1)) * TILE, w);
     }
     const int key0 = j * ATT_KB;
     if (!CAUSAL || key0 <= q_first + 31) {  // wave-uniform: tiles entirely above the diagonal contribute nothing
@@ -160,9 +173,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
       for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.0f;
+        // K fragments one k-step ahead of their MFMAs, pinned by scheduling barriers (left alone the scheduler emits
+        // ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma per MFMA and pays the LDS latency every time)
+        bf8 ka = row_frag<D>(kt, 32 * kb, 0, lane);
 #pragma unroll
-        for (int t = 0; t < KT; ++t)
-          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(kt, 32 * kb, t, lane), qf[t], sacc[kb], 0, 0, 0);
+        for (int t = 0; t < KT; ++t) {
+          bf8 kn = ka;
+          if (t + 1 < KT) kn = row_frag<D>(kt, 32 * kb, t + 1, lane);
+          __builtin_amdgcn_sched_barrier(0);
+          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[t], sacc[kb], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          ka = kn;
+        }
       }
       if (DIAG) {
         asm volatile("" : "+v"(sacc[0][0]), "+v"(sacc[1][15]));
@@ -208,19 +230,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           const bf8 pf = acc_frag(sacc[kb], s);
+          bf8 fa = tr_frag<D>(vt, 32 * kb + 16 * s, 0, lane);
 #pragma unroll
-          for (int d = 0; d < DB; ++d)
-            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(vt, 32 * kb + 16 * s, 32 * d, lane), pf, oacc[d], 0, 0, 0);
+          for (int d = 0; d < DB; ++d) {
+            bf8 fn = fa;
+            if (d + 1 < DB) fn = tr_frag<D>(vt, 32 * kb + 16 * s, 32 * (d + 1), lane);
+            __builtin_amdgcn_sched_barrier(0);
+            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, pf, oacc[d], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            fa = fn;
+          }
         }
     }
     if (DIAG) {
       asm volatile("" : "+v"(oacc[0][0]), "+v"(oacc[DB - 1][15]));
     }
     MI_STAMP(2)
-    if (more) {
-      stage_store<D>(kreg, lds + ((j + 1) & 1) * TILE, tid);
-      stage_store<D>(vreg, lds + (2 + ((j + 1) & 1)) * TILE, tid);
-    }
+    dma_wait_all();  // the next tile has landed (this wave's share; the barrier covers the others')
     MI_STAMP(3)
     __syncthreads();
     MI_STAMP(4)
@@ -343,11 +369,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[d][i] = 0.0f;
 
-  v4i kreg[D / 32], vreg[D / 32];
-  stage_load<D>(kreg, kbase, k_ts, tid);
-  stage_load<D>(vreg, vbase, v_ts, tid);
-  stage_store<D>(kreg, lds, tid);
-  stage_store<D>(vreg, lds + 2 * TILE, tid);
+  // K / V tiles of 64 keys go global -> LDS by DMA, double-buffered: tile j + 1 is requested at the top of tile j
+  const rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (int)((((int64_t)S - 1) * k_ts + D) * 2), 0x00020000);
+  const rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (int)((((int64_t)S - 1) * v_ts + D) * 2), 0x00020000);
+  int kvo[D / 32], vvo[D / 32];
+  dma_voffsets<D>(kvo, k_ts, tid);
+  dma_voffsets<D>(vvo, v_ts, tid);
+  stage_dma<D>(rsK, kvo, 0, lds, w);
+  stage_dma<D>(rsV, vvo, 0, lds + 2 * TILE, w);
+  dma_wait_all();
   __syncthreads();
 
   for (int j = 0; j < ntiles; ++j) {
@@ -355,42 +385,60 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const uint16_t* __r
     const char* vt = lds + (2 + (j & 1)) * TILE;
     const bool more = j + 1 < ntiles;
     if (more) {
-      stage_load<D>(kreg, kbase + (int64_t)(j + 1) * ATT_KB * k_ts, k_ts, tid);
-      stage_load<D>(vreg, vbase + (int64_t)(j + 1) * ATT_KB * v_ts, v_ts, tid);
+      stage_dma<D>(rsK, kvo, (int)((int64_t)(j + 1) * ATT_KB * k_ts * 2), lds + ((j + 1) & 1) * TILE, w);
+      stage_dma<D>(rsV, vvo, (int)((int64_t)(j + 1) * ATT_KB * v_ts * 2), lds + (2 + ((j + 1) & 1)) * TILE, w);
     }
     const int key0 = j * ATT_KB;
-    if (!CAUSAL || key0 <= q_first + 31) {
+    auto block = [&](const int kb) {  // one 32-key block of the tile against this wave's 32 query rows
+      f16v sacc, pacc;
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        if (CAUSAL && key0 + 32 * kb > q_first + 31) continue;  // wave-uniform
-        f16v sacc, pacc;
+      for (int i = 0; i < 16; ++i) { sacc[i] = 0.0f; pacc[i] = 0.0f; }
+      // fragments one k-step ahead of their MFMAs, pinned by scheduling barriers: left alone the scheduler emits
+      // ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma for every single MFMA and the LDS latency is paid 48 times per tile
+      constexpr int PF = 1;  // k-steps of look-ahead (2 measured the same; 1 leaves 10 VGPRs of slack under the 256 of 2 waves per SIMD)
+      bf8 kr[KT], vr[KT];    // (fully unrolled: only PF + 1 of each are live at a time)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { sacc[i] = 0.0f; pacc[i] = 0.0f; }
+      for (int t = 0; t < PF; ++t) {
+        kr[t] = row_frag<D>(kt, 32 * kb, t, lane);
+        vr[t] = row_frag<D>(vt, 32 * kb, t, lane);
+      }
 #pragma unroll
-        for (int t = 0; t < KT; ++t) {
-          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(kt, 32 * kb, t, lane), qf[t], sacc, 0, 0, 0);
-          pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<D>(vt, 32 * kb, t, lane), dof[t], pacc, 0, 0, 0);
+      for (int t = 0; t < KT; ++t) {
+        if (t + PF < KT) {
+          kr[t + PF] = row_frag<D>(kt, 32 * kb, t + PF, lane);
+          vr[t + PF] = row_frag<D>(vt, 32 * kb, t + PF, lane);
         }
-        const bool diag = CAUSAL && key0 + 32 * kb + 31 > q_first;
+        __builtin_amdgcn_sched_barrier(0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[t], qf[t], sacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr[t], dof[t], pacc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const bool diag = CAUSAL && key0 + 32 * kb + 31 > q_first;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[i], c, -my_lse));
-          if (diag && key0 + 32 * kb + acc_row(i, h) > qrow) p = 0.0f;
-          sacc[i] = p * (pacc[i] - dl);
-        }
+      for (int i = 0; i < 16; ++i) {
+        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[i], c, -my_lse));
+        if (diag && key0 + 32 * kb + acc_row(i, h) > qrow) p = 0.0f;
+        sacc[i] = p * (pacc[i] - dl);
+      }
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const bf8 dsf = acc_frag(sacc, s);
+      for (int s = 0; s < 2; ++s) {
+        const bf8 dsf = acc_frag(sacc, s);
+        bf8 fa = tr_frag<D>(kt, 32 * kb + 16 * s, 0, lane);
 #pragma unroll
-          for (int d = 0; d < DB; ++d)
-            acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<D>(kt, 32 * kb + 16 * s, 32 * d, lane), dsf, acc[d], 0, 0, 0);
+        for (int d = 0; d < DB; ++d) {
+          bf8 fn = fa;
+          if (d + 1 < DB) fn = tr_frag<D>(kt, 32 * kb + 16 * s, 32 * (d + 1), lane);
+          __builtin_amdgcn_sched_barrier(0);
+          acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, dsf, acc[d], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          fa = fn;
         }
       }
-    }
-    if (more) {
-      stage_store<D>(kreg, lds + ((j + 1) & 1) * TILE, tid);
-      stage_store<D>(vreg, lds + (2 + ((j + 1) & 1)) * TILE, tid);
-    }
+    };
+    // (wave-uniform tests: blocks entirely above the diagonal contribute nothing)
+    if (!CAUSAL || key0 <= q_first + 31) block(0);
+    if (!CAUSAL || key0 + 32 <= q_first + 31) block(1);
+    dma_wait_all();  // the next tile has landed (this wave's share; the barrier covers the others')
     __syncthreads();
   }
   store_rows_from_accT<D>(acc, scale, lds + w * (32 * D * 2), dq + ((int64_t)b * S + q_first) * dq_ts + (int64_t)head * D, dq_ts, lane);
