@@ -593,6 +593,8 @@ extern "C" int mi_attn_fwd(const void* q, const void* k, const void* v, void* o,
   MI_CHECK_ARG(D == 128 || D == 64, "mi_attn_fwd: head_dim %d not supported (64, 128)", D);
   MI_CHECK_ARG(S >= 128 && S % 128 == 0, "mi_attn_fwd: seq %d must be a multiple of 128", S);
   MI_CHECK_ARG(q_ts % 8 == 0 && k_ts % 8 == 0 && v_ts % 8 == 0 && o_ts % 8 == 0, "mi_attn_fwd: token strides must be multiples of 8");
+  MI_CHECK_ARG((int64_t)S * k_ts * 2 < (1LL << 31) && (int64_t)S * v_ts * 2 < (1LL << 31) && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0,
+               "mi_attn_fwd: one batch of K / V must span < 2 GiB and be 16-byte aligned (32-bit buffer offsets of the LDS DMA)");
   MI_CHECK_ARG(H <= 65535 && B <= 65535, "mi_attn_fwd: grid too large");
   const float c = scale * 1.4426950408889634f;
   dim3 grid(S / mi::ATT_QB, H, B), block(256);
@@ -634,6 +636,8 @@ extern "C" int mi_attn_bwd(const void* q, const void* k, const void* v, const vo
   MI_CHECK_ARG(D == 128 || D == 64, "mi_attn_bwd: head_dim %d not supported (64, 128)", D);
   MI_CHECK_ARG(S >= 128 && S % 128 == 0, "mi_attn_bwd: seq %d must be a multiple of 128", S);
   MI_CHECK_ARG((q_ts | k_ts | v_ts | o_ts | do_ts | dq_ts | dk_ts | dv_ts) % 8 == 0, "mi_attn_bwd: token strides must be multiples of 8");
+  MI_CHECK_ARG((int64_t)S * k_ts * 2 < (1LL << 31) && (int64_t)S * v_ts * 2 < (1LL << 31) && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0,
+               "mi_attn_bwd: one batch of K / V must span < 2 GiB and be 16-byte aligned (32-bit buffer offsets of the LDS DMA)");
   MI_CHECK_ARG(H <= 65535 && B <= 65535, "mi_attn_bwd: grid too large");
   const float c = scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;

@@ -124,7 +124,8 @@ def _flash_ok(q, k, v, causal: bool, dropout: float) -> bool:
     B, S, H, D = q.shape
     if D not in (64, 128) or S % 128 or S < 128 or H % k.shape[2]:
         return False
-    return all(t.stride(3) == 1 and t.stride(2) == D and t.stride(0) == S * t.stride(1) and t.stride(1) % 8 == 0 for t in (q, k, v))
+    return all(t.stride(3) == 1 and t.stride(2) == D and t.stride(0) == S * t.stride(1) and t.stride(1) % 8 == 0
+               and S * t.stride(1) * 2 < 2 ** 31 and t.data_ptr() % 16 == 0 for t in (q, k, v))
 
 
 class DotProductAttention(torch.nn.Module):
