@@ -218,9 +218,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
         }
       l = l * alpha + psum;
 #pragma unroll
-      for (int d = 0; d < DB; ++d)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+      for (int d = 0; d < DB; ++d) oacc[d] = oacc[d] * alpha;  // whole-vector form: lowered to v_pk_mul_f32 (2 floats per issue slot)
       if (DIAG) {
         asm volatile("" : "+v"(oacc[0][0]), "+v"(sacc[1][15]), "+v"(l));
       }
