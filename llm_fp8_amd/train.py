@@ -115,7 +115,7 @@ def wrap_distributed(model: torch.nn.Module, cfg: TrainingConfig, device) -> tor
         return model
     if mode == "replicated":
         from .distributed import GradArenaDP
-        return GradArenaDP(model)
+        return GradArenaDP(model, bucket_mb=float(os.environ.get("LLM_FP8_AMD_BUCKET_MB", "256")))
     if mode == "ddp":
         from torch.nn.parallel import DistributedDataParallel as DDP
         return DDP(model, device_ids=[device.index] if device.type == "cuda" else None, gradient_as_bucket_view=True)
