@@ -8,7 +8,8 @@ FSDP / DDP stay available through `--sharding_mode fsdp_full | ddp` (train.wrap_
 
 Layout: one contiguous bf16 (per dtype) arena holds every parameter's gradient, ordered by when backward produces it
 (last module first; q|k|v of one projection adjacent, so the fused wgrad GEMM of `_FP8LinearFn` writes all three in one
-launch -- module._wgrad_out).  The arena is cut into buckets of >= `bucket_mb`; when the last gradient of a bucket has
+launch -- module._wgrad_out).  The arena is cut into buckets of >= `bucket_mb` (a quarter of that for the last 15 % of the
+arena, which backward finishes last); when the last gradient of a bucket has
 been accumulated the bucket is all-reduced (AVG) on RCCL's stream while backward continues: few, large collectives, as
 xGMI's point-to-point links want (7 x ~153 GB/s per GPU, ring collectives are per-link bound).  The optimiser
 (optim.ClippedAdamW) then reads gradients at addresses that never change between steps.
@@ -127,7 +128,10 @@ class GradArenaDP(torch.nn.Module):
             b.params.append(p)
             b.end = off + -(-p.numel() // _ALIGN) * _ALIGN
             self._bucket_of[id(p)] = b
-            if (b.end - b.start) * arena.element_size() >= bucket_bytes:
+            # the buckets that close last (the first layers: the tail of backward) are a quarter of the size, so that the
+            # all-reduce still in flight when backward ends is short
+            cap = bucket_bytes if off < 0.85 * sizes[a] else max(bucket_bytes // 4, 1)
+            if (b.end - b.start) * arena.element_size() >= cap:
                 del open_bucket[a]
             p.register_post_accumulate_grad_hook(self._on_grad)
         for b in self.buckets:
