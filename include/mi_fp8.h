@@ -171,6 +171,15 @@ int mi_gemm_mxfp8(const void* A, const void* SA, const void* B, const void* SB, 
 int mi_rope_qkv(void* fused_bf16, void* q_bf16, void* k_bf16, void* v_bf16, const float* cos_tab,
                 const float* sin_tab, int64_t rows, int64_t seq, int n_q_heads, int n_kv_heads, int head_dim,
                 int backward, void* stream);
+/*
+ * RoPE backward (mi_rope_qkv with backward = 1) fused with mi_cast_amax of its result: dq [rows, n_q*D], dk, dv
+ * [rows, n_kv*D] bf16 -> the FP8 copies y [rows, W] / yT [W, rows] (W = (n_q + 2 n_kv) * D) of the fused gradient d(qkv),
+ * which is grad_output of the q|k|v projection (te_llama.py:45-56: `layernorm_qkv` feeding the rotary attention core), plus
+ * its amax.  The bf16 gradient is never written.  Bytes and amax equal the two-kernel sequence bit for bit.  head_dim 128.
+ */
+int mi_rope_qkv_bwd_cast(const void* dq_bf16, const void* dk_bf16, const void* dv_bf16, const float* cos_tab, const float* sin_tab,
+                         void* y_fp8, void* yT_fp8, const float* scale, float* amax, int64_t rows, int64_t seq, int n_q_heads,
+                         int n_kv_heads, int head_dim, int fmt, void* stream);
 
 /*
  * K10  SwiGLU fused with the FP8 cast of fc2's input  [TE LayerNormMLP activation="swiglu", te_llama.py:58-63].

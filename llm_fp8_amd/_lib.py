@@ -28,6 +28,7 @@ SIGNATURES = {
     "mi_mxfp8_quantize": [_p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],
     "mi_mxfp8_quantize_ex": [_p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_i64, _c_int, _p],
     "mi_rope_qkv": [_p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_int, _p],
+    "mi_rope_qkv_bwd_cast": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_int, _p],
     "mi_swiglu_cast": [_p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],
     "mi_dswiglu_cast": [_p, _p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],
     "mi_rmsnorm_stats": [_p, _p, _c_i64, _c_i64, ctypes.c_float, _p],

@@ -74,6 +74,113 @@ __global__ __launch_bounds__(256) void rope_qkv_kernel(uint16_t* __restrict__ fu
   }
 }
 
+// RoPE backward fused with the FP8 cast of the result: the fused gradient d(qkv) [rows, W] is grad_output of the q|k|v
+// projection, whose backward would read it once more just to quantise it.  Here it leaves as FP8 (y [rows, W] and
+// yT [W, rows]) + amax and is never written in bf16.  Values are rounded to bf16 before the cast, so the bytes equal
+// mi_rope_qkv(backward) followed by mi_cast_amax bit for bit.  head_dim 128: a wave owns 64 rows x one whole q/k head
+// (the two 64-column halves x1 | x2 that rotate into each other) or 64 rows x 64 columns of the v part.
+template <int FMT, bool WRITE_Y, bool WRITE_T>
+__global__ __launch_bounds__(256) void rope_bwd_cast_kernel(const uint16_t* __restrict__ dq, const uint16_t* __restrict__ dk,
+                                                            const uint16_t* __restrict__ dv, const float* __restrict__ cosT,
+                                                            const float* __restrict__ sinT, uint8_t* __restrict__ y,
+                                                            uint8_t* __restrict__ yT, const float* __restrict__ scale_p,
+                                                            float* amax_out, int rows, int seq, int nq, int nk) {
+  constexpr int D = 128, half = 64;
+  __shared__ float s_amax[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int W = (nq + 2 * nk) * D;
+  const int units = (nq + nk) + 2 * nk;  // per 64-row block: rotated heads, then 64-column tiles of v
+  const int64_t u_all = (int64_t)blockIdx.x * 4 + wave;
+  const int rb = (int)(u_all / units), u = (int)(u_all % units);
+  const int r0 = rb * 64 + (lane >> 3) * 8, lc = (lane & 7) * 8;
+  const float scale = *scale_p;
+  float amax = 0.0f;
+  auto emit = [&](const float (&f)[8][8], int c0) {  // 8 x 8 block (rows r0.., fused columns c0..) -> FP8 both ways
+    u32 lo[8], hi[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, (f[i][j] != f[i][j]) ? 0.0f : fabsf(f[i][j]));
+      lo[i] = cvt4_fp8<FMT>(f[i][0] * scale, f[i][1] * scale, f[i][2] * scale, f[i][3] * scale);
+      hi[i] = cvt4_fp8<FMT>(f[i][4] * scale, f[i][5] * scale, f[i][6] * scale, f[i][7] * scale);
+    }
+    if (WRITE_Y) {
+      uint8_t* dst = y + (int64_t)r0 * W + c0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<uint2*>(dst + (int64_t)i * W) = make_uint2(lo[i], hi[i]);
+    }
+    if (WRITE_T) {
+      u32 a[4], b[4], c[4], d[4];
+      transpose4x4(lo[0], lo[1], lo[2], lo[3], a[0], a[1], a[2], a[3]);
+      transpose4x4(lo[4], lo[5], lo[6], lo[7], b[0], b[1], b[2], b[3]);
+      transpose4x4(hi[0], hi[1], hi[2], hi[3], c[0], c[1], c[2], c[3]);
+      transpose4x4(hi[4], hi[5], hi[6], hi[7], d[0], d[1], d[2], d[3]);
+      uint8_t* dst = yT + (int64_t)c0 * rows + r0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<uint2*>(dst + (int64_t)j * rows) = make_uint2(a[j], b[j]);
+        *reinterpret_cast<uint2*>(dst + (int64_t)(j + 4) * rows) = make_uint2(c[j], d[j]);
+      }
+    }
+  };
+  auto bf16_round = [](float v) { return __uint_as_float(float_to_bf16_bits(v) << 16); };
+  if (r0 < rows) {  // rows is a multiple of 8: a lane's 8 rows are all in or all out
+    if (u < nq + nk) {
+      const int hd = u;
+      const uint16_t* src = hd < nq ? dq + ((int64_t)r0 * nq + hd) * D : dk + ((int64_t)r0 * nk + (hd - nq)) * D;
+      const int64_t rstride = (int64_t)(hd < nq ? nq : nk) * D;
+      float f1[8][8], f2[8][8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const v4i a = *reinterpret_cast<const v4i*>(src + i * rstride + lc);
+        const v4i b = *reinterpret_cast<const v4i*>(src + i * rstride + half + lc);
+        const int pos = (r0 + i) % seq;
+        float c[8], sn[8];
+        *reinterpret_cast<v4f*>(c) = *reinterpret_cast<const v4f*>(cosT + (int64_t)pos * half + lc);
+        *reinterpret_cast<v4f*>(c + 4) = *reinterpret_cast<const v4f*>(cosT + (int64_t)pos * half + lc + 4);
+        *reinterpret_cast<v4f*>(sn) = *reinterpret_cast<const v4f*>(sinT + (int64_t)pos * half + lc);
+        *reinterpret_cast<v4f*>(sn + 4) = *reinterpret_cast<const v4f*>(sinT + (int64_t)pos * half + lc + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const u32 wa = (u32)a[j], wb = (u32)b[j];
+          const float x1l = __uint_as_float(wa << 16), x1h = __uint_as_float(wa & 0xFFFF0000u);
+          const float x2l = __uint_as_float(wb << 16), x2h = __uint_as_float(wb & 0xFFFF0000u);
+          // same expressions as rope_qkv_kernel<1> (sgn = -1), then its bf16 rounding
+          const float cl = c[2 * j], ch = c[2 * j + 1], sl = -1.0f * sn[2 * j], sh = -1.0f * sn[2 * j + 1];
+          f1[i][2 * j] = bf16_round(x1l * cl - x2l * sl);
+          f1[i][2 * j + 1] = bf16_round(x1h * ch - x2h * sh);
+          f2[i][2 * j] = bf16_round(x2l * cl + x1l * sl);
+          f2[i][2 * j + 1] = bf16_round(x2h * ch + x1h * sh);
+        }
+      }
+      emit(f1, hd * D + lc);
+      emit(f2, hd * D + half + lc);
+    } else {
+      const int tc = u - (nq + nk);  // 64-column tile of the v part
+      float f[8][8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const v4i a = *reinterpret_cast<const v4i*>(dv + (int64_t)(r0 + i) * (nk * D) + tc * 64 + lc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f[i][2 * j] = __uint_as_float((u32)a[j] << 16);
+          f[i][2 * j + 1] = __uint_as_float((u32)a[j] & 0xFFFF0000u);
+        }
+      }
+      emit(f, (nq + nk) * D + tc * 64 + lc);
+    }
+  }
+  if (amax_out != nullptr) {
+    amax = wave_max(amax);
+    if (lane == 0) s_amax[wave] = amax;
+    __syncthreads();
+    if (tid == 0) {
+      const float m = fmaxf(fmaxf(s_amax[0], s_amax[1]), fmaxf(s_amax[2], s_amax[3]));
+      if (m > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(amax_out), __float_as_uint(m));
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ SwiGLU (+cast)
 __device__ __forceinline__ float sigmoidf_(float g) { return 1.0f / (1.0f + __expf(-g)); }
 
@@ -524,6 +631,41 @@ extern "C" int mi_rope_qkv(void* fused_bf16, void* q_bf16, void* k_bf16, void* v
                        (uint16_t*)q_bf16, (uint16_t*)k_bf16, (uint16_t*)v_bf16, cos_tab, sin_tab, (int)rows, (int)seq, n_q_heads,
                        n_kv_heads, head_dim);
   MI_CHECK_LAUNCH("mi_rope_qkv launch");
+  return MI_OK;
+}
+
+extern "C" int mi_rope_qkv_bwd_cast(const void* dq_bf16, const void* dk_bf16, const void* dv_bf16, const float* cos_tab,
+                                    const float* sin_tab, void* y_fp8, void* yT_fp8, const float* scale, float* amax, int64_t rows,
+                                    int64_t seq, int n_q_heads, int n_kv_heads, int head_dim, int fmt, void* stream) {
+  MI_CHECK_ARG(dq_bf16 && dk_bf16 && dv_bf16 && cos_tab && sin_tab && scale, "mi_rope_qkv_bwd_cast: null pointer");
+  MI_CHECK_ARG(y_fp8 || yT_fp8, "mi_rope_qkv_bwd_cast: at least one of y, yT must be non-null");
+  MI_CHECK_ARG(head_dim == 128, "mi_rope_qkv_bwd_cast: head_dim %d not supported (128)", head_dim);
+  MI_CHECK_ARG(n_q_heads >= 1 && n_kv_heads >= 1 && seq >= 1 && rows >= 0 && rows % 8 == 0 && rows < (1LL << 31),
+               "mi_rope_qkv_bwd_cast: bad shape (rows a multiple of 8)");
+  MI_CHECK_ARG(((uintptr_t)dq_bf16 % 16) == 0 && ((uintptr_t)dk_bf16 % 16) == 0 && ((uintptr_t)dv_bf16 % 16) == 0 &&
+                   ((uintptr_t)cos_tab % 16) == 0 && ((uintptr_t)sin_tab % 16) == 0 && ((uintptr_t)y_fp8 % 8) == 0 &&
+                   ((uintptr_t)yT_fp8 % 8) == 0, "mi_rope_qkv_bwd_cast: misaligned pointer");
+  MI_CHECK_ARG(fmt == MI_FMT_E4M3 || fmt == MI_FMT_E5M2, "mi_rope_qkv_bwd_cast: bad fmt %d", fmt);
+  if (rows == 0) return MI_OK;
+  const int64_t units = ((rows + 63) / 64) * (int64_t)(n_q_heads + 3 * n_kv_heads);
+  dim3 grid((unsigned)((units + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define MI_RC(FMTv)                                                                                                          \
+  if (y_fp8 && yT_fp8)                                                                                                       \
+    hipLaunchKernelGGL((mi::rope_bwd_cast_kernel<FMTv, true, true>), grid, block, 0, st, (const uint16_t*)dq_bf16,           \
+                       (const uint16_t*)dk_bf16, (const uint16_t*)dv_bf16, cos_tab, sin_tab, (uint8_t*)y_fp8, (uint8_t*)yT_fp8, \
+                       scale, amax, (int)rows, (int)seq, n_q_heads, n_kv_heads);                                             \
+  else if (y_fp8)                                                                                                            \
+    hipLaunchKernelGGL((mi::rope_bwd_cast_kernel<FMTv, true, false>), grid, block, 0, st, (const uint16_t*)dq_bf16,          \
+                       (const uint16_t*)dk_bf16, (const uint16_t*)dv_bf16, cos_tab, sin_tab, (uint8_t*)y_fp8, (uint8_t*)yT_fp8, \
+                       scale, amax, (int)rows, (int)seq, n_q_heads, n_kv_heads);                                             \
+  else                                                                                                                       \
+    hipLaunchKernelGGL((mi::rope_bwd_cast_kernel<FMTv, false, true>), grid, block, 0, st, (const uint16_t*)dq_bf16,          \
+                       (const uint16_t*)dk_bf16, (const uint16_t*)dv_bf16, cos_tab, sin_tab, (uint8_t*)y_fp8, (uint8_t*)yT_fp8, \
+                       scale, amax, (int)rows, (int)seq, n_q_heads, n_kv_heads);
+  if (fmt == MI_FMT_E4M3) { MI_RC(MI_FMT_E4M3) } else { MI_RC(MI_FMT_E5M2) }
+#undef MI_RC
+  MI_CHECK_LAUNCH("mi_rope_qkv_bwd_cast launch");
   return MI_OK;
 }
 

@@ -8,13 +8,14 @@ csrc/mi_attn.hip for the shapes of the reference's configs (causal, head_dim 64 
 torch `scaled_dot_product_attention` otherwise."""
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
 import torch.nn.functional as F
 
 from . import ops
-from .module import LayerNormLinear, Linear
+from .module import DyHandoff, LayerNormLinear, Linear
 
 __all__ = ["RotaryPositionEmbedding", "apply_rotary_pos_emb", "DotProductAttention", "MultiheadAttention"]
 
@@ -78,16 +79,19 @@ def _cos_sin_tables(freqs: torch.Tensor, seq: int):
 
 
 class _RoPESplitFn(torch.autograd.Function):
-    """qkv [B,S,W] -> q [B,S,h,d], k, v [B,S,g,d] with RoPE on q, k: one HIP launch each way (mi_rope_qkv)."""
+    """qkv [B,S,W] -> q [B,S,h,d], k, v [B,S,g,d] with RoPE on q, k: one HIP launch each way (mi_rope_qkv).
+    `handoff` (module.DyHandoff, optional): the q|k|v projection that produced `qkv` has announced how its backward quantises
+    grad_output; backward then emits that FP8 gradient directly (mi_rope_qkv_bwd_cast) and returns an unwritten placeholder."""
 
     @staticmethod
-    def forward(ctx, qkv, cos, sin, n_q, n_kv, d):
+    def forward(ctx, qkv, cos, sin, n_q, n_kv, d, handoff=None):
         B, S, W = qkv.shape
         x = qkv.reshape(B * S, W)
         x = x if x.is_contiguous() else x.contiguous()
         q, k, v = ops.rope_qkv_forward(x, cos, sin, n_q, n_kv, d, S)
         ctx.save_for_backward(cos, sin)
         ctx.meta = (B, S, n_q, n_kv, d)
+        ctx.handoff = handoff
         return q.view(B, S, n_q, d), k.view(B, S, n_kv, d), v.view(B, S, n_kv, d)
 
     @staticmethod
@@ -95,9 +99,16 @@ class _RoPESplitFn(torch.autograd.Function):
         cos, sin = ctx.saved_tensors
         B, S, n_q, n_kv, d = ctx.meta
         T = B * S
+        h = ctx.handoff
+        if h is not None and h.offered() and d == 128 and T % 8 == 0:
+            g8, g8t = ops.rope_qkv_backward_cast(dq.reshape(T, n_q * d), dk.reshape(T, n_kv * d), dv.reshape(T, n_kv * d), cos, sin,
+                                                 n_q, n_kv, d, S, h.scale, h.amax, h.fmt, want_y=h.want_y, want_t=h.want_t)
+            g = torch.empty((B, S, (n_q + 2 * n_kv) * d), dtype=torch.bfloat16, device=dq.device)  # placeholder: never written
+            h.put(g8, g8t, g)
+            return g, None, None, None, None, None, None
         g = ops.rope_qkv_backward(dq.reshape(T, n_q * d), dk.reshape(T, n_kv * d), dv.reshape(T, n_kv * d), cos, sin,
                                   n_q, n_kv, d, S)
-        return g.view(B, S, -1), None, None, None, None, None
+        return g.view(B, S, -1), None, None, None, None, None, None
 
 
 class _FlashAttnFn(torch.autograd.Function):
@@ -204,18 +215,24 @@ class MultiheadAttention(torch.nn.Module):
         if _with_skip:
             if not self.input_layernorm:
                 return self._attend(self.qkv(hidden_states), attention_mask, rotary_pos_emb), hidden_states
-            qkv, skip = self.layernorm_qkv(hidden_states, _with_skip=True, _rstd=_rstd)
-            return self._attend(qkv, attention_mask, rotary_pos_emb), skip
+            # the rotary split's backward hands the projection its grad_output already in FP8 (module.DyHandoff): only
+            # when the two are wired back to back right here
+            handoff = DyHandoff() if (rotary_pos_emb is not None and hidden_states.is_cuda and torch.is_grad_enabled()
+                                      and os.environ.get("LLM_FP8_AMD_NO_DY_HANDOFF") != "1") else None
+            qkv, skip = self.layernorm_qkv(hidden_states, _with_skip=True, _rstd=_rstd, _dy_handoff=handoff)
+            return self._attend(qkv, attention_mask, rotary_pos_emb, handoff), skip
         qkv = self.layernorm_qkv(hidden_states) if self.input_layernorm else self.qkv(hidden_states)
         return self._attend(qkv, attention_mask, rotary_pos_emb)
 
-    def _attend(self, qkv: torch.Tensor, attention_mask, rotary_pos_emb) -> torch.Tensor:
+    def _attend(self, qkv: torch.Tensor, attention_mask, rotary_pos_emb, handoff=None) -> torch.Tensor:
         if (rotary_pos_emb is not None and not isinstance(rotary_pos_emb, (tuple, list)) and qkv.is_cuda
                 and qkv.dtype == torch.bfloat16 and self.qkv_format == "bshd" and self.d % 16 == 0
                 and rotary_pos_emb.shape[-1] == self.d):
             cos, sin = _cos_sin_tables(rotary_pos_emb, qkv.shape[1])
-            q, k, v = _RoPESplitFn.apply(qkv, cos, sin, self.h, self.g, self.d)
+            q, k, v = _RoPESplitFn.apply(qkv, cos, sin, self.h, self.g, self.d, handoff)
             return self.proj(self.core_attention(q, k, v, attention_mask))
+        if handoff is not None:
+            handoff.scale = None  # not the fused rotary path: withdraw the offer, the projection quantises its own grad_output
         q, k, v = torch.split(qkv, self.split, dim=-1)
         a, b = qkv.shape[0], qkv.shape[1]
         q = q.reshape(a, b, self.h, self.d)

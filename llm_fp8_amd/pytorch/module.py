@@ -34,13 +34,45 @@ def _as_bf16_2d(t: torch.Tensor) -> torch.Tensor:
     return t2.contiguous()
 
 
+class DyHandoff:
+    """grad_output of an FP8 Linear delivered already quantised by the op that produces it.
+
+    The Linear's forward `offer`s what its backward will quantise grad_output with (delayed scaling: scale and amax slot are
+    known in advance); the producer's backward (attention._RoPESplitFn) then emits the FP8 copies itself, `put`s them here and
+    returns an UNWRITTEN bf16 placeholder as the autograd gradient; the Linear's backward `take`s the copies and never reads
+    the placeholder.  One object per forward call, private to the module that wires the two together: nothing else may sit
+    between them in the graph.  `take` checks that the gradient it was handed is that placeholder and fails loudly otherwise."""
+    __slots__ = ("scale", "amax", "fmt", "want_y", "want_t", "fp8", "ptr")
+
+    def __init__(self):
+        self.scale = self.amax = self.fmt = self.fp8 = self.ptr = None
+        self.want_y = self.want_t = False
+
+    def offer(self, scale, amax, fmt, want_y, want_t):
+        self.scale, self.amax, self.fmt, self.want_y, self.want_t = scale, amax, fmt, want_y, want_t
+
+    def offered(self) -> bool:
+        return self.scale is not None and (self.want_y or self.want_t)
+
+    def put(self, g8, g8t, placeholder: torch.Tensor):
+        self.fp8, self.ptr = (g8, g8t), placeholder.untyped_storage().data_ptr()
+
+    def take(self, dy: torch.Tensor):
+        if dy.untyped_storage().data_ptr() != self.ptr:
+            raise RuntimeError("DyHandoff: the gradient reaching the Linear is not the producer's placeholder "
+                               "(an op was inserted between the q|k|v projection and the rotary split)")
+        fp8, self.fp8, self.ptr = self.fp8, None, None
+        return fp8
+
+
 class _GemmSpec:
     """Everything non-tensor a GEMM site needs: recipe, meta windows, slot base, update trigger."""
     __slots__ = ("recipe", "meta_fwd", "meta_bwd", "g", "fmt_fwd", "fmt_bwd", "trigger_bwd_update", "training", "eps",
-                 "wcache", "first_mb", "with_skip", "rstd")
+                 "wcache", "first_mb", "with_skip", "rstd", "dy_handoff")
 
     def __init__(self, recipe, meta_fwd, meta_bwd, g, trigger_bwd_update, training, eps=1e-5, wcache=None, first_mb=None,
-                 with_skip=False, rstd=None):
+                 with_skip=False, rstd=None, dy_handoff=None):
+        self.dy_handoff = dy_handoff
         self.eps = eps
         # rstd: RMSNorm statistics of the input already computed by the producer of the input (residual_add_stats)
         self.rstd = rstd
@@ -205,6 +237,8 @@ class _FP8LinearFn(torch.autograd.Function):
             # scale_inv as of quantisation time: the arena is updated at autocast exit, before backward
             sinv = (mf.scale_inv_snapshot()[3 * g:3 * g + 1], siw) if (need_wgrad or need_dgrad) else None
             ctx.saved_fp8 = (x8t, None, w8t, None, sinv)
+            if spec.dy_handoff is not None and bias is None and spec.meta_bwd is not None and (need_wgrad or need_dgrad):
+                spec.dy_handoff.offer(spec.meta_bwd.scale(2 * g), spec.meta_bwd.amax(2 * g), spec.fmt_bwd, need_dgrad, need_wgrad)
         ctx.spec, ctx.ns, ctx.x_shape, ctx.x_dtype = spec, ns, x.shape, x.dtype
         ctx.w_dtypes = [w.dtype for w in weights]
         ctx.w_refs = weights if need_wgrad else None  # the Parameters themselves (not saved tensors): for _wgrad_out
@@ -236,7 +270,9 @@ class _FP8LinearFn(torch.autograd.Function):
                 dw = ops.gemm_mxfp8(gt8, gts, xt8, xts, spec.fmt_bwd, spec.fmt_fwd, out=_wgrad_out(ctx.w_refs, xt8.shape[0]))
         else:
             mb, g = spec.meta_bwd, spec.g
-            if ctx.has_bias:  # the bias gradient rides on the cast of dy
+            if spec.dy_handoff is not None and spec.dy_handoff.fp8 is not None:
+                g8, g8t = spec.dy_handoff.take(dy)  # already quantised by the op that produced it (dy is a placeholder)
+            elif ctx.has_bias:  # the bias gradient rides on the cast of dy
                 g8, g8t, cs = ops.cast_amax(g2, mb.scale(2 * g), mb.amax(2 * g), spec.fmt_bwd,
                                             want_y=ctx.need_dgrad, want_t=ctx.need_wgrad, want_colsum=True)
                 db_fused = ops.colsum_finish(cs, ctx.bias_dtype)
@@ -606,7 +642,7 @@ class LayerNormLinear(_FP8Module):
             return _rmsnorm(x, self.layer_norm_weight, self.eps, self.zero_centered_gamma)
         return _layernorm(x, self.layer_norm_weight, self.layer_norm_bias, self.eps, self.zero_centered_gamma)
 
-    def forward(self, inp: torch.Tensor, is_first_microbatch=None, _with_skip: bool = False, _rstd=None):
+    def forward(self, inp: torch.Tensor, is_first_microbatch=None, _with_skip: bool = False, _rstd=None, _dy_handoff=None):
         """`_with_skip` (extension used by MultiheadAttention / the decoder layer): returns (out, skip) where `skip` carries
         `inp` for the residual add, its gradient fused into the RMSNorm backward when the fused-norm path is active.
         `_rstd`: (rstd, eps) of `inp` from residual_add_stats, used instead of a statistics pass when eps matches."""
@@ -615,7 +651,8 @@ class LayerNormLinear(_FP8Module):
         if st is not None and _can_fuse_norm(self, st[0], inp) and not self.return_layernorm_output:
             recipe, mf, mb, first = st
             return _FP8LinearFn.apply(inp, b, _GemmSpec(recipe, mf, mb, 0, first, self.training, self.eps, self._wcache,
-                                                        is_first_microbatch, with_skip=_with_skip, rstd=_usable_rstd(_rstd, inp, self.eps)),
+                                                        is_first_microbatch, with_skip=_with_skip, rstd=_usable_rstd(_rstd, inp, self.eps),
+                                                        dy_handoff=_dy_handoff),
                                       self.layer_norm_weight, *ws)
         ln = self._norm(inp)
         if st is None:

@@ -266,6 +266,28 @@ def rope_qkv_backward(dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, cos:
     return out
 
 
+def rope_qkv_backward_cast(dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
+                           n_q: int, n_kv: int, head_dim: int, seq: int, scale: torch.Tensor, amax: Optional[torch.Tensor],
+                           fmt: int, want_y: bool = True, want_t: bool = True):
+    """rope_qkv_backward + cast_amax of its result in one launch: (g8 [T, W], g8T [W, T]); the bf16 d(qkv) is never written."""
+    _dev(dq, dk, dv, cos, sin, scale, amax)
+    dq, dk, dv = (t.contiguous() for t in (dq, dk, dv))
+    T = dq.shape[0]
+    W = (n_q + 2 * n_kv) * head_dim
+    y = torch.empty((T, W), dtype=torch.uint8, device=dq.device) if want_y else None
+    yT = torch.empty((W, T), dtype=torch.uint8, device=dq.device) if want_t else None
+    args = (dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), cos.data_ptr(), sin.data_ptr(), _ptr(y), _ptr(yT), scale.data_ptr(),
+            _ptr(amax), T, seq, n_q, n_kv, head_dim, fmt, _stream())
+    t = KernelTimer.active
+    if t is None:
+        rc = _lib.load().mi_rope_qkv_bwd_cast(*args)
+    else:
+        with t.span("cast_amax", f"rope {T}x{W}", float(T * W), float(T * W * (2 + (y is not None) + (yT is not None)))):
+            rc = _lib.load().mi_rope_qkv_bwd_cast(*args)
+    _lib.check(rc, "mi_rope_qkv_bwd_cast")
+    return y, yT
+
+
 def swiglu_cast(h: torch.Tensor, scale: torch.Tensor, amax: Optional[torch.Tensor], fmt: int, want_y: bool = True,
                 want_t: bool = True):
     """K10 fwd.  h bf16 [R, 2F] -> (act8 [R, F], act8T [F, R]) with act = silu(gate) * up computed in fp32."""

@@ -380,6 +380,32 @@ def test_rope_qkv_split_and_merge_vs_oracle(ops, dev, B, S, nq, nkv, D):
     assert np.all(np.abs(back[:, :nq * D].float().cpu().numpy() - O.bf16_bits_to_f32(dq_ref)) <= 2.0 ** -7 * np.abs(O.bf16_bits_to_f32(dq_ref)) + 1e-5 * np.abs(xf).max())
 
 
+@pytest.mark.parametrize("fmt", [O.E5M2, O.E4M3])
+@pytest.mark.parametrize("shape", [(2, 128, 24, 8), (1, 72, 4, 2), (3, 64, 8, 8)])
+def test_rope_backward_cast_is_bitwise_the_two_kernel_sequence(ops, dev, fmt, shape):
+    """mi_rope_qkv_bwd_cast == mi_rope_qkv(backward) followed by mi_cast_amax: FP8 bytes both ways and the amax, bit for bit
+    (ragged 64-row blocks, GQA and MHA head counts, NaN / inf in the gradients)."""
+    B, S, nq, nkv = shape
+    D, T = 128, shape[0] * shape[1]
+    g = torch.Generator().manual_seed(S + nq)
+    dq = (torch.randn(T, nq * D, generator=g) * 0.3).to(torch.bfloat16).to(dev)
+    dk = (torch.randn(T, nkv * D, generator=g) * 3.0).to(torch.bfloat16).to(dev)
+    dv = torch.randn(T, nkv * D, generator=g).to(torch.bfloat16).to(dev)
+    dq[1, 5] = float("nan")
+    dv[3, 7] = float("inf")
+    ang = torch.outer(torch.arange(S, dtype=torch.float32), 1.0 / (10000.0 ** (torch.arange(0, D, 2, dtype=torch.float32) / D)))
+    cos, sin = torch.cos(ang).contiguous().to(dev), torch.sin(ang).contiguous().to(dev)
+    scale = torch.tensor([37.0], device=dev)
+    ref = ops.rope_qkv_backward(dq, dk, dv, cos, sin, nq, nkv, D, S)
+    a_ref = torch.zeros(1, device=dev)
+    y_ref, t_ref = ops.cast_amax(ref, scale, a_ref, fmt)
+    a = torch.zeros(1, device=dev)
+    y, yt = ops.rope_qkv_backward_cast(dq, dk, dv, cos, sin, nq, nkv, D, S, scale, a, fmt)
+    assert torch.equal(y, y_ref) and torch.equal(yt, t_ref) and torch.equal(a, a_ref) and a.item() > 0
+    y2, none = ops.rope_qkv_backward_cast(dq, dk, dv, cos, sin, nq, nkv, D, S, scale, None, fmt, want_t=False)
+    assert none is None and torch.equal(y2, y_ref)
+
+
 # ----------------------------------------------------------------------------------------- K9 RMSNorm -> FP8
 @pytest.mark.parametrize("shape", [(8, 512), (137, 1024), (8192, 3072), (3, 8192), (64, 4104)])
 def test_add_rmsnorm_stats_matches_add_then_stats(ops, dev, shape):
