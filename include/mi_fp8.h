@@ -228,6 +228,13 @@ int mi_ce_forward(const void* logits_bf16, const int64_t* labels, float* lse, fl
                   int64_t cols, void* stream);
 int mi_ce_backward(const void* logits_bf16, const int64_t* labels, const float* lse, const float* gscale,
                    void* dlogits_bf16, int64_t rows, int64_t cols, void* stream);
+/*
+ * mi_ce_backward fused with mi_cast_amax of its result: d(logits) leaves as the FP8 copies y [rows, cols] / yT [cols, rows]
+ * (+ amax) that the lm_head Linear's backward quantises its grad_output into (train_fp8.py:276-280: `outputs.loss` of the
+ * FP8 lm_head); the bf16 d(logits) is never written.  Bytes and amax equal the two-kernel sequence bit for bit.
+ */
+int mi_ce_backward_cast(const void* logits_bf16, const int64_t* labels, const float* lse, const float* gscale, void* y_fp8,
+                        void* yT_fp8, const float* scale, float* amax, int64_t rows, int64_t cols, int fmt, void* stream);
 
 /*
  * Optimiser step of the reference loop (train_fp8.py:288-291: clip_grad_norm_(model.parameters(), 1.0) then

@@ -36,6 +36,7 @@ SIGNATURES = {
     "mi_rmsnorm_bwd": [_p, _p, _p, _p, _p, _p, _p, _c_int, _c_i64, _c_i64, _p],
     "mi_ce_forward": [_p, _p, _p, _p, _c_i64, _c_i64, _p],
     "mi_ce_backward": [_p, _p, _p, _p, _p, _c_i64, _c_i64, _p],
+    "mi_ce_backward_cast": [_p, _p, _p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],
     "mi_sumsq_bf16": [_p, _c_i64, _p, _c_int, _p],
     "mi_sumsq_bf16_multi": [_p, _c_int, _p, _c_int, _c_int, _p, _p],
     "mi_adamw_bf16_multi": [_p, _c_int, _p, _c_int, _c_int, _p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,

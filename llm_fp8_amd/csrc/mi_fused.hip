@@ -606,6 +606,76 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const uint16_t* __restrict_
   }
 }
 
+// Cross-entropy backward fused with the FP8 cast of its result: d(logits) [rows, cols] is grad_output of the lm_head
+// Linear (2.1 GB in bf16 for Llama-3.2-3B at 8192 tokens), whose backward would read it once more just to quantise it.
+// Same arithmetic as ce_bwd_kernel, rounded to bf16, then mi_cast_amax's: the FP8 bytes and the amax equal the two-kernel
+// sequence bit for bit.  One 128 x 128 tile per workgroup, 8 x 8 block per lane (the tiling of norm_cast_kernel).
+template <int FMT, bool WRITE_Y, bool WRITE_T>
+__global__ __launch_bounds__(256) void ce_bwd_cast_kernel(const uint16_t* __restrict__ x, const int64_t* __restrict__ labels,
+                                                          const float* __restrict__ lse, const float* __restrict__ gscale,
+                                                          uint8_t* __restrict__ y, uint8_t* __restrict__ yT,
+                                                          const float* __restrict__ scale_p, float* amax_out, int rows, int cols,
+                                                          int tiles_c) {
+  __shared__ float s_amax[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile_r = blockIdx.x / tiles_c, tile_c = blockIdx.x % tiles_c;
+  const int r0 = tile_r * 128 + (wave >> 1) * 64 + (lane >> 3) * 8;
+  const int c0 = tile_c * 128 + (wave & 1) * 64 + (lane & 7) * 8;
+  const float scale = *scale_p, g0 = *gscale;
+  float amax = 0.0f;
+  if ((r0 < rows) && (c0 < cols)) {
+    u32 lo[8], hi[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int64_t lab = labels[r0 + i];
+      const bool valid = lab >= 0 && lab < cols;
+      const float gs = valid ? g0 : 0.0f;
+      const float l = lse[r0 + i];
+      const v4i raw = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(x + (int64_t)(r0 + i) * cols + c0));
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float p0 = __expf(__uint_as_float((u32)raw[j] << 16) - l), p1 = __expf(__uint_as_float((u32)raw[j] & 0xFFFF0000u) - l);
+        if (c0 + 2 * j == lab) p0 -= 1.0f;
+        if (c0 + 2 * j + 1 == lab) p1 -= 1.0f;
+        f[2 * j] = __uint_as_float(float_to_bf16_bits(p0 * gs) << 16);
+        f[2 * j + 1] = __uint_as_float(float_to_bf16_bits(p1 * gs) << 16);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, (f[j] != f[j]) ? 0.0f : fabsf(f[j]));
+      lo[i] = cvt4_fp8<FMT>(f[0] * scale, f[1] * scale, f[2] * scale, f[3] * scale);
+      hi[i] = cvt4_fp8<FMT>(f[4] * scale, f[5] * scale, f[6] * scale, f[7] * scale);
+    }
+    if (WRITE_Y) {
+      uint8_t* dst = y + (int64_t)r0 * cols + c0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<uint2*>(dst + (int64_t)i * cols) = make_uint2(lo[i], hi[i]);
+    }
+    if (WRITE_T) {
+      u32 a[4], b[4], c[4], d[4];
+      transpose4x4(lo[0], lo[1], lo[2], lo[3], a[0], a[1], a[2], a[3]);
+      transpose4x4(lo[4], lo[5], lo[6], lo[7], b[0], b[1], b[2], b[3]);
+      transpose4x4(hi[0], hi[1], hi[2], hi[3], c[0], c[1], c[2], c[3]);
+      transpose4x4(hi[4], hi[5], hi[6], hi[7], d[0], d[1], d[2], d[3]);
+      uint8_t* dst = yT + (int64_t)c0 * rows + r0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<uint2*>(dst + (int64_t)j * rows) = make_uint2(a[j], b[j]);
+        *reinterpret_cast<uint2*>(dst + (int64_t)(j + 4) * rows) = make_uint2(c[j], d[j]);
+      }
+    }
+  }
+  if (amax_out != nullptr) {
+    amax = wave_max(amax);
+    if (lane == 0) s_amax[wave] = amax;
+    __syncthreads();
+    if (tid == 0) {
+      const float m = fmaxf(fmaxf(s_amax[0], s_amax[1]), fmaxf(s_amax[2], s_amax[3]));
+      if (m > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(amax_out), __float_as_uint(m));
+    }
+  }
+}
+
 }  // namespace mi
 
 extern "C" int mi_rope_qkv(void* fused_bf16, void* q_bf16, void* k_bf16, void* v_bf16, const float* cos_tab,
@@ -835,5 +905,34 @@ extern "C" int mi_ce_backward(const void* logits_bf16, const int64_t* labels, co
   hipLaunchKernelGGL(mi::ce_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)logits_bf16, labels,
                      lse, gscale, (uint16_t*)dlogits_bf16, (int)cols);
   MI_CHECK_LAUNCH("mi_ce_backward launch");
+  return MI_OK;
+}
+
+extern "C" int mi_ce_backward_cast(const void* logits_bf16, const int64_t* labels, const float* lse, const float* gscale,
+                                   void* y_fp8, void* yT_fp8, const float* scale, float* amax, int64_t rows, int64_t cols, int fmt,
+                                   void* stream) {
+  MI_CHECK_ARG(logits_bf16 && labels && lse && gscale && scale, "mi_ce_backward_cast: null pointer");
+  MI_CHECK_ARG(y_fp8 || yT_fp8, "mi_ce_backward_cast: at least one of y, yT must be non-null");
+  MI_CHECK_ARG(rows >= 0 && cols > 0 && rows % 8 == 0 && cols % 8 == 0 && rows < (1LL << 31) && cols < (1LL << 31),
+               "mi_ce_backward_cast: rows and cols must be multiples of 8");
+  MI_CHECK_ARG(((uintptr_t)logits_bf16 % 16) == 0 && ((uintptr_t)y_fp8 % 8) == 0 && ((uintptr_t)yT_fp8 % 8) == 0,
+               "mi_ce_backward_cast: misaligned pointer");
+  MI_CHECK_ARG(fmt == MI_FMT_E4M3 || fmt == MI_FMT_E5M2, "mi_ce_backward_cast: bad fmt %d", fmt);
+  if (rows == 0) return MI_OK;
+  const int tiles_r = (int)((rows + 127) / 128), tiles_c = (int)((cols + 127) / 128);
+  MI_CHECK_ARG((int64_t)tiles_r * tiles_c < (1LL << 31), "mi_ce_backward_cast: shape too large");
+  dim3 grid((unsigned)(tiles_r * tiles_c)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define MI_CC(FMTv, WY, WT)                                                                                              \
+  hipLaunchKernelGGL((mi::ce_bwd_cast_kernel<FMTv, WY, WT>), grid, block, 0, st, (const uint16_t*)logits_bf16, labels, lse, \
+                     gscale, (uint8_t*)y_fp8, (uint8_t*)yT_fp8, scale, amax, (int)rows, (int)cols, tiles_c)
+#define MI_CC_F(FMTv)                                    \
+  if (y_fp8 && yT_fp8) MI_CC(FMTv, true, true);          \
+  else if (y_fp8) MI_CC(FMTv, true, false);              \
+  else MI_CC(FMTv, false, true);
+  if (fmt == MI_FMT_E4M3) { MI_CC_F(MI_FMT_E4M3) } else { MI_CC_F(MI_FMT_E5M2) }
+#undef MI_CC_F
+#undef MI_CC
+  MI_CHECK_LAUNCH("mi_ce_backward_cast launch");
   return MI_OK;
 }

@@ -580,8 +580,16 @@ class Linear(_FP8Module):
         if st is None:
             return F.linear(inp, self.weight.to(inp.dtype), None if self.bias is None else self.bias.to(inp.dtype))
         recipe, mf, mb, first = st
-        spec = _GemmSpec(recipe, mf, mb, 0, first, self.training, wcache=self._wcache, first_mb=is_first_microbatch)
-        return _FP8LinearFn.apply(inp, self.bias, spec, None, self.weight)
+        # `offer_dy_handoff` (set on the lm_head by train.prepare_model): the output carries a DyHandoff through which the op
+        # that consumes it directly (loss.causal_lm_loss) can deliver this layer's grad_output already quantised
+        handoff = DyHandoff() if (getattr(self, "offer_dy_handoff", False) and self.training and torch.is_grad_enabled()
+                                  and self.bias is None) else None
+        spec = _GemmSpec(recipe, mf, mb, 0, first, self.training, wcache=self._wcache, first_mb=is_first_microbatch,
+                         dy_handoff=handoff)
+        y = _FP8LinearFn.apply(inp, self.bias, spec, None, self.weight)
+        if handoff is not None and handoff.offered():
+            y._mi_dy_handoff = handoff
+        return y
 
     def extra_repr(self):
         return f"in_features={self.in_features}, out_features={self.out_features}, bias={self.use_bias}"

@@ -76,6 +76,9 @@ def prepare_model(model: torch.nn.Module, cfg: TrainingConfig) -> torch.nn.Modul
         llama.apply_fp8_autowrap(model, recipe)
     if torch.cuda.is_available() and os.environ.get("LLM_FP8_AMD_HF_LOSS") != "1":
         from .loss import causal_lm_loss
+        head = model.get_output_embeddings() if hasattr(model, "get_output_embeddings") else None
+        if type(head).__name__ == "Linear" and type(head).__module__.startswith("llm_fp8_amd"):
+            head.offer_dy_handoff = True  # causal_lm_loss delivers the lm_head's grad_output in FP8 (loss._CEFn)
         try:
             model.loss_function = causal_lm_loss  # HF resolves `self.loss_function(logits=..., labels=..., vocab_size=...)`
         except Exception:

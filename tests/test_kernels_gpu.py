@@ -406,6 +406,36 @@ def test_rope_backward_cast_is_bitwise_the_two_kernel_sequence(ops, dev, fmt, sh
     assert none is None and torch.equal(y2, y_ref)
 
 
+@pytest.mark.parametrize("fmt", [O.E5M2, O.E4M3])
+def test_ce_backward_cast_is_bitwise_the_two_kernel_sequence(dev, ops, fmt):
+    """mi_ce_backward_cast == mi_ce_backward followed by mi_cast_amax (FP8 bytes both ways, amax), ragged tiles, ignored rows."""
+    from llm_fp8_amd import _lib
+    lib = _lib.load()
+    T, V = 200, 1160  # neither a multiple of 128
+    g = torch.Generator().manual_seed(3)
+    logits = (torch.randn(T, V, generator=g) * 3).to(torch.bfloat16).to(dev)
+    labels = torch.randint(0, V, (T,), generator=g).to(dev)
+    labels[::7] = -100
+    st = torch.cuda.current_stream().cuda_stream
+    lse = torch.empty(T, dtype=torch.float32, device=dev)
+    rows = torch.empty(T, dtype=torch.float32, device=dev)
+    _lib.check(lib.mi_ce_forward(logits.data_ptr(), labels.data_ptr(), lse.data_ptr(), rows.data_ptr(), T, V, st), "fwd")
+    gscale = torch.tensor([0.37], device=dev)
+    d = torch.empty_like(logits)
+    _lib.check(lib.mi_ce_backward(logits.data_ptr(), labels.data_ptr(), lse.data_ptr(), gscale.data_ptr(), d.data_ptr(), T, V, st), "bwd")
+    scale = torch.tensor([4096.0], device=dev)
+    a_ref = torch.zeros(1, device=dev)
+    y_ref, t_ref = ops.cast_amax(d, scale, a_ref, fmt)
+    y = torch.zeros((T, V), dtype=torch.uint8, device=dev)
+    yt = torch.zeros((V, T), dtype=torch.uint8, device=dev)
+    a = torch.zeros(1, device=dev)
+    _lib.check(lib.mi_ce_backward_cast(logits.data_ptr(), labels.data_ptr(), lse.data_ptr(), gscale.data_ptr(), y.data_ptr(),
+                                       yt.data_ptr(), scale.data_ptr(), a.data_ptr(), T, V, fmt, st), "fused")
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref) and torch.equal(yt, t_ref) and torch.equal(a, a_ref) and a.item() > 0
+    assert int((y_ref != 0).sum()) > T  # the comparison is not vacuous
+
+
 # ----------------------------------------------------------------------------------------- K9 RMSNorm -> FP8
 @pytest.mark.parametrize("shape", [(8, 512), (137, 1024), (8192, 3072), (3, 8192), (64, 4104)])
 def test_add_rmsnorm_stats_matches_add_then_stats(ops, dev, shape):

@@ -528,6 +528,50 @@ def test_decoder_layer_skip_fusion_matches_plain_residual(te, dev, scenario):
         assert rel < (3e-2 if name == "dgamma" else 1e-2), f"{name}: {rel:.4g}"  # only the rounding of dx + dskip moves (and what it re-quantises to upstream)
 
 
+@pytest.mark.parametrize("scenario", ["default", "mxfp8"])
+def test_grad_output_handoffs_are_bitwise_the_unfused_path(te, dev, scenario, monkeypatch):
+    """module.DyHandoff (RoPE backward -> q|k|v projection, cross-entropy backward -> lm_head: grad_output delivered in FP8 by
+    the op that produces it, placeholder through autograd) against the ordinary route: same losses, weights and amax
+    histories after 3 optimiser steps, bit for bit."""
+    from llm_fp8_amd import train
+    from llm_fp8_amd.pytorch.fp8 import FP8GlobalStateManager as G
+    from llm_fp8_amd.pytorch import ops as _ops
+
+    def run(disable):
+        G.reset()
+        if disable:
+            monkeypatch.setenv("LLM_FP8_AMD_NO_DY_HANDOFF", "1")
+        else:
+            monkeypatch.delenv("LLM_FP8_AMD_NO_DY_HANDOFF", raising=False)
+        calls = {"rope": 0}
+        orig = _ops.rope_qkv_backward_cast
+        monkeypatch.setattr(_ops, "rope_qkv_backward_cast", lambda *a, **k: (calls.__setitem__("rope", calls["rope"] + 1), orig(*a, **k))[1])
+        cfg = train.TrainingConfig(model_name="llama-3.2-3b", batch_size=2, max_seq_length=128, mixed_precision="fp8",
+                                   fp8_scenario=scenario, use_te=True, sharding_mode="none", num_hidden_layers=2, vocab_size=2048,
+                                   learning_rate=1e-3, num_warmup_steps=0)
+        torch.manual_seed(21)
+        device = torch.device(dev)
+        model = train.prepare_model(train.create_model(cfg, device), cfg)
+        opt, sched = train.create_optimizer(model, cfg)
+        model.train()
+        gen = torch.Generator(device=device).manual_seed(8)
+        losses = [train.train_step(model, train.synthetic_batch(cfg, 2048, device, gen), opt, sched, cfg).item() for _ in range(3)]
+        hist = torch.cat([a.hist[:, :a.used].reshape(-1) for a in G._arenas.values()]).clone()
+        flat = torch.cat([p.detach().reshape(-1).view(torch.int16) for p in model.parameters()]).clone()
+        monkeypatch.setattr(_ops, "rope_qkv_backward_cast", orig)
+        return losses, hist, flat, calls["rope"]
+
+    try:
+        l1, h1, w1, n1 = run(False)
+        l0, h0, w0, n0 = run(True)
+    finally:
+        G.reset()
+    # delayed-scaling attention takes the fused RoPE route (head_dim 128); under MXFP8 recipes only the lm_head hand-off is live
+    assert n0 == 0 and (n1 == 6 if scenario == "default" else n1 == 0), (n1, n0)
+    assert l1 == l0, (l1, l0)
+    assert torch.equal(h1, h0) and torch.equal(w1, w0)
+
+
 def test_residual_stats_handoff_between_decoder_layers(te, dev):
     """The residual add hands the next norm's rstd over (inside a layer as an argument, across layers on the tensor); a
     tensor modified in place, or a norm with another eps, ignores the hand-off."""
