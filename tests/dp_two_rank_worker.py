@@ -87,7 +87,11 @@ def main():
     torch.cuda.synchronize()
     flat = torch.cat([p.detach().float().reshape(-1) for p in params])
     out.update(losses=losses, checksum=float(flat.double().sum().item()), absum=float(flat.double().abs().sum().item()))
-    print(json.dumps(out), flush=True)
+    outs = [None] * world  # one writer: two processes printing to the same pipe can interleave their lines
+    dist.all_gather_object(outs, out)
+    if rank == 0:
+        for o in outs:
+            print(json.dumps(o), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
