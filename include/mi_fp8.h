@@ -256,6 +256,16 @@ int mi_sumsq_bf16_multi(const int64_t* table, int n_tensors, const int32_t* chun
 int mi_adamw_bf16_multi(const int64_t* table, int n_tensors, const int32_t* chunks, int n_chunks, int chunk_elems,
                         const float* grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay,
                         int64_t step, void* stream);
+/*
+ * Embedding weight gradient added in place: grad[id, :] += alpha * sum_{tokens t with ids[t] == id} dY[t, :]   (bf16, fp32
+ * sums).  The tied lm_head / embedding table of the reference's Llama models (te_llama.py: `tie_word_embeddings`) already
+ * holds the lm_head wgrad when the embedding's backward runs; this replaces a dense [vocab, hidden] scatter + add by a pass
+ * over the touched rows.  sorted_ids / perm: the token ids sorted ascending (stable) and the permutation that sorts them
+ * (row perm[i] of dY belongs to sorted_ids[i]); ids outside [0, vocab) and padding_idx (-1: none) are skipped.
+ * Deterministic (fixed summation order, one writer per row).
+ */
+int mi_embedding_grad_add(void* grad_bf16, const void* dy_bf16, const int64_t* sorted_ids, const int64_t* perm, int64_t tokens,
+                          int64_t hidden, int64_t vocab, float alpha, int64_t padding_idx, void* stream);
 int mi_adamw_bf16(void* p_bf16, const void* g_bf16, void* exp_avg_bf16, void* exp_avg_sq_bf16, int64_t n,
                   const float* grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay,
                   int64_t step, void* stream);

@@ -186,17 +186,15 @@ class GradArenaDP(torch.nn.Module):
                     dist.all_gather_into_tensor(dy_all, dy, group=self.group)
                 else:
                     ids_all, dy_all = ids, dy
-                dense = torch.ops.aten.embedding_dense_backward(dy_all, ids_all, p.shape[0],
-                                                                -1 if emb.padding_idx is None else emb.padding_idx, False)
                 buf = p._mi_grad_buf
                 if p.grad is None:          # untied table: nothing else wrote its slot in this pass
-                    torch.mul(dense, 1.0 / self.world, out=buf)
+                    buf.zero_()
                     p.grad = buf
-                else:                       # tied to lm_head: the averaged wgrad is already there
-                    if p.grad.data_ptr() != buf.data_ptr():
-                        buf.copy_(p.grad)
-                        p.grad = buf
-                    buf.add_(dense, alpha=1.0 / self.world)
+                elif p.grad.data_ptr() != buf.data_ptr():
+                    buf.copy_(p.grad)
+                    p.grad = buf
+                # tied to lm_head: the averaged wgrad is already there; either way the rows are added in place
+                add_embedding_rows_(buf, dy_all, ids_all, 1.0 / self.world, emb.padding_idx)
 
     # ------------------------------------------------------------------------------------------------ backward side
     def _on_grad(self, p: torch.nn.Parameter):
@@ -274,6 +272,54 @@ class GradArenaDP(torch.nn.Module):
 
 # debug / rehearsal: run the collectives even at world size 1 (exercises the RCCL stream hand-over on a one-GPU box)
 _FORCE_COLLECTIVES = os.environ.get("LLM_FP8_AMD_FORCE_COLLECTIVES") == "1"
+
+
+def add_embedding_rows_(grad: torch.Tensor, dy: torch.Tensor, ids: torch.Tensor, alpha: float, padding_idx) -> None:
+    """grad [V, H] += alpha * (rows of dy scattered by ids), in place and deterministic.  On the GPU in bf16 this is
+    mi_embedding_grad_add (touched rows only); otherwise aten's embedding_dense_backward + a dense add."""
+    pad = -1 if padding_idx is None else int(padding_idx)
+    if grad.is_cuda and grad.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and grad.is_contiguous() and grad.shape[1] % 8 == 0:
+        from .pytorch import ops
+        ops.embedding_grad_add_(grad, dy, ids, alpha, pad)
+        return
+    dense = torch.ops.aten.embedding_dense_backward(dy.reshape(-1, dy.shape[-1]).to(grad.dtype).contiguous(), ids.reshape(-1),
+                                                    grad.shape[0], pad, False)
+    grad.add_(dense, alpha=alpha)
+
+
+class _LocalEmbeddingGrad:
+    """Single-process counterpart of GradArenaDP's row-sparse embedding reduction: the embedding's backward adds its rows
+    straight into the table's `.grad` (which, for a table tied to lm_head, already holds the lm_head wgrad by then) instead of
+    materialising a dense [vocab, hidden] gradient that autograd then adds to the other one (Llama-3.2-3B: 788 MB each)."""
+
+    def __init__(self):
+        self._anchor = None
+
+    def forward(self, emb, ids):
+        if not (torch.is_grad_enabled() and emb.weight.requires_grad):
+            return F.embedding(ids, emb.weight, emb.padding_idx)
+        if self._anchor is None or self._anchor.device != emb.weight.device:
+            self._anchor = torch.zeros(1, device=emb.weight.device, requires_grad=True)
+        return _DeferredEmbeddingGrad.apply(self._anchor, ids, emb.weight.detach(), self, emb)
+
+    def _defer_embedding_grad(self, emb, ids, dy):
+        p = emb.weight
+        with torch.no_grad():
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            add_embedding_rows_(p.grad, dy.reshape(-1, dy.shape[-1]), ids.reshape(-1), 1.0, emb.padding_idx)
+
+
+def install_local_embedding_grad(module: torch.nn.Module) -> int:
+    """For a model trained WITHOUT a data-parallel wrapper (wrappers reduce `.grad` from hooks that fire before the embedding's
+    backward has run): route every plain nn.Embedding's weight gradient through _LocalEmbeddingGrad.  Returns how many."""
+    sink, n = _LocalEmbeddingGrad(), 0
+    for m in module.modules():
+        if (type(m) is torch.nn.Embedding and m.weight.requires_grad and m.weight.is_cuda and m.max_norm is None and not m.sparse
+                and not m.scale_grad_by_freq and "forward" not in m.__dict__):
+            m.forward = functools.partial(sink.forward, m)
+            n += 1
+    return n
 
 
 def replicated_state_bytes(module: torch.nn.Module, moment_bytes: int = 4) -> int:

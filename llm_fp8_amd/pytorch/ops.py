@@ -266,6 +266,20 @@ def rope_qkv_backward(dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, cos:
     return out
 
 
+def embedding_grad_add_(grad: torch.Tensor, dy: torch.Tensor, ids: torch.Tensor, alpha: float = 1.0, padding_idx: int = -1) -> None:
+    """grad [V, H] bf16 += alpha * scatter-sum of dy [T, H] bf16 rows by ids [T] (int64), in place, deterministic."""
+    _dev(grad, dy, ids)
+    assert grad.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and grad.is_contiguous() and grad.dim() == 2
+    dy = dy.reshape(-1, dy.shape[-1])
+    dy = dy if dy.is_contiguous() else dy.contiguous()
+    ids = ids.reshape(-1).to(torch.int64)
+    assert dy.shape == (ids.numel(), grad.shape[1])
+    sorted_ids, perm = torch.sort(ids, stable=True)
+    rc = _lib.load().mi_embedding_grad_add(grad.data_ptr(), dy.data_ptr(), sorted_ids.data_ptr(), perm.data_ptr(), ids.numel(),
+                                           grad.shape[1], grad.shape[0], float(alpha), int(padding_idx), _stream())
+    _lib.check(rc, "mi_embedding_grad_add")
+
+
 def rope_qkv_backward_cast(dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
                            n_q: int, n_kv: int, head_dim: int, seq: int, scale: torch.Tensor, amax: Optional[torch.Tensor],
                            fmt: int, want_y: bool = True, want_t: bool = True):

@@ -108,14 +108,22 @@ def resolve_sharding_mode(mode: str, model: torch.nn.Module, device) -> str:
     return "replicated" if fits_replicated(model, device) else "fsdp_full"
 
 
+def _single_process(model: torch.nn.Module, device) -> torch.nn.Module:
+    """No data-parallel wrapper: the embedding table's gradient rows are added in place (distributed._LocalEmbeddingGrad)."""
+    if getattr(device, "type", "cpu") == "cuda" and os.environ.get("LLM_FP8_AMD_DENSE_EMBEDDING_GRAD") != "1":
+        from .distributed import install_local_embedding_grad
+        install_local_embedding_grad(model)
+    return model
+
+
 def wrap_distributed(model: torch.nn.Module, cfg: TrainingConfig, device) -> torch.nn.Module:
     """DistributedWrapper (train_multi_gpu.py:328-510)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or cfg.sharding_mode == "none":
-        return model
+        return _single_process(model, device)
     mode = resolve_sharding_mode(cfg.sharding_mode, model, device)
     if mode == "none":
-        return model
+        return _single_process(model, device)
     if mode == "replicated":
         from .distributed import GradArenaDP
         return GradArenaDP(model, bucket_mb=float(os.environ.get("LLM_FP8_AMD_BUCKET_MB", "256")))

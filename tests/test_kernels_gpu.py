@@ -436,6 +436,33 @@ def test_ce_backward_cast_is_bitwise_the_two_kernel_sequence(dev, ops, fmt):
     assert int((y_ref != 0).sum()) > T  # the comparison is not vacuous
 
 
+def test_embedding_grad_add_in_place(ops, dev):
+    """mi_embedding_grad_add: grad[id] += alpha * sum of the rows of dY with that id -- repeated ids, untouched rows left alone,
+    padding / out-of-range ids skipped, result within one bf16 ulp of an fp64 scatter, bitwise reproducible."""
+    g = torch.Generator().manual_seed(12)
+    V, H, T = 300, 264, 1000
+    grad0 = torch.randn(V, H, generator=g).to(torch.bfloat16)
+    dy = (torch.randn(T, H, generator=g) * 0.7).to(torch.bfloat16)
+    ids = torch.randint(0, 40, (T,), generator=g)            # few distinct ids: long runs of repeats
+    ids[::13] = 299
+    ids[5] = 7_000                                            # out of range: ignored
+    ids[6] = 17                                               # padding_idx below
+    alpha = 0.5
+    ok = (ids < V) & (ids != 17)
+    want = grad0.double().index_add_(0, ids[ok], alpha * dy[ok].double())
+    outs = []
+    for _ in range(2):
+        grad = grad0.clone().to(dev)
+        ops.embedding_grad_add_(grad, dy.to(dev), ids.to(dev), alpha=alpha, padding_idx=17)
+        outs.append(grad.cpu())
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    got = outs[0].double()
+    ulp = torch.maximum(want.abs(), got.abs()).clamp_min(1e-30).log2().floor().exp2() * 2.0 ** -7
+    assert float(((got - want).abs() / ulp).max()) <= 1.0
+    untouched = torch.ones(V, dtype=torch.bool); untouched[ids[ok]] = False
+    assert untouched.sum() > 100 and torch.equal(outs[0][untouched].view(torch.int16), grad0[untouched].view(torch.int16))
+
+
 # ----------------------------------------------------------------------------------------- K9 RMSNorm -> FP8
 @pytest.mark.parametrize("shape", [(8, 512), (137, 1024), (8192, 3072), (3, 8192), (64, 4104)])
 def test_add_rmsnorm_stats_matches_add_then_stats(ops, dev, shape):

@@ -572,6 +572,39 @@ def test_grad_output_handoffs_are_bitwise_the_unfused_path(te, dev, scenario, mo
     assert torch.equal(h1, h0) and torch.equal(w1, w0)
 
 
+def test_local_embedding_grad_rows_added_in_place(te, dev):
+    """distributed.install_local_embedding_grad (what train.wrap_distributed does without a wrapper): the tied table's gradient
+    = lm_head wgrad + embedding rows, the rows added in place; against autograd's dense route on the same model and batch."""
+    from llm_fp8_amd import train
+    from llm_fp8_amd.distributed import install_local_embedding_grad
+    from llm_fp8_amd.pytorch.fp8 import FP8GlobalStateManager as G
+    grads = []
+    for install in (False, True):
+        G.reset()
+        cfg = train.TrainingConfig(model_name="llama-3.2-1b", batch_size=2, max_seq_length=128, mixed_precision="fp8",
+                                   fp8_scenario="default", use_te=True, sharding_mode="none", num_hidden_layers=1, vocab_size=1024,
+                                   learning_rate=1e-3, num_warmup_steps=0)
+        torch.manual_seed(4)
+        device = torch.device(dev)
+        model = train.prepare_model(train.create_model(cfg, device), cfg)
+        if install:
+            assert install_local_embedding_grad(model) == 1
+        model.train()
+        gen = torch.Generator(device=device).manual_seed(2)
+        batch = train.synthetic_batch(cfg, 1024, device, gen)
+        model(**batch).loss.backward()
+        table = model.get_input_embeddings().weight
+        assert model.get_output_embeddings().weight is table
+        grads.append(table.grad.float().clone())
+    G.reset()
+    dense, inplace = grads
+    err = (dense - inplace).abs()
+    # (the dense route rounds twice and sums repeated tokens' rows in bf16: long runs of repeats are checked against fp64 in
+    # test_kernels_gpu.py::test_embedding_grad_add_in_place instead)
+    tol = 2.0 ** -6 * torch.maximum(dense.abs(), inplace.abs()) + 2e-3 * dense.abs().max()
+    assert float((err / tol).max()) <= 1.0 and float(inplace.abs().sum()) > 0
+
+
 def test_residual_stats_handoff_between_decoder_layers(te, dev):
     """The residual add hands the next norm's rstd over (inside a layer as an argument, across layers on the tensor); a
     tensor modified in place, or a norm with another eps, ignores the hand-off."""
