@@ -149,6 +149,15 @@ int mi_mxfp8_swiglu_quantize(const void* h_bf16, void* y_row, void* s_row, void*
                              int64_t F, int fmt, void* stream);
 int mi_mxfp8_dswiglu_quantize(const void* h_bf16, const void* dact_bf16, void* y_row, void* s_row, void* y_colT,
                               void* s_colT, float* colsum, int64_t rows, int64_t F, int fmt, void* stream);
+/*
+ * RoPE backward (mi_rope_qkv, backward = 1) fused with mi_mxfp8_quantize of its result: the MXFP8 grad_output of the q|k|v
+ * projection under MXFP8BlockScaling (te_llama_mxfp8.py:28-29,86), straight from the attention gradients dq / dk / dv; the
+ * bf16 d(qkv) [rows, W] is never written.  Outputs as mi_mxfp8_quantize for a [rows, W] tensor, W = (n_q + 2 n_kv) * 128;
+ * equal to the two-kernel sequence bit for bit.
+ */
+int mi_mxfp8_rope_bwd_quantize(const void* dq_bf16, const void* dk_bf16, const void* dv_bf16, const float* cos_tab,
+                               const float* sin_tab, void* y_row, void* s_row, void* y_colT, void* s_colT, int64_t rows,
+                               int64_t seq, int n_q_heads, int n_kv_heads, int head_dim, int fmt, void* stream);
 
 /*
  * K8  block-scaled MXFP8 GEMM (v_mfma_scale_f32_16x16x128_f8f6f4 with per-32 E8M0 scales)

@@ -27,6 +27,7 @@ SIGNATURES = {
                     _c_int, _c_int, _c_int, _c_int, _p],
     "mi_mxfp8_quantize": [_p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],
     "mi_mxfp8_quantize_ex": [_p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_i64, _c_int, _p],
+    "mi_mxfp8_rope_bwd_quantize": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_int, _p],
     "mi_rope_qkv": [_p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_int, _p],
     "mi_rope_qkv_bwd_cast": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_int, _p],
     "mi_swiglu_cast": [_p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],

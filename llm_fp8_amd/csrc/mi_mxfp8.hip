@@ -44,7 +44,9 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
                                                           const float* __restrict__ aux32, uint8_t* __restrict__ y_row,
                                                           uint8_t* __restrict__ s_row, uint8_t* __restrict__ y_colT,
                                                           uint8_t* __restrict__ s_colT, float* __restrict__ colsum, int rows,
-                                                          int cols, int tiles_c, int ldr) {
+                                                          int cols, int tiles_c, int ldr, const uint16_t* __restrict__ e0 = nullptr,
+                                                          const float* __restrict__ e1 = nullptr, int i0 = 0, int i1 = 0,
+                                                          int i2 = 0) {
   // ldr: leading dimension of s_row / y_colT (= rows, or the row count of a larger operand this tensor is a row-block of)
   __shared__ float s_col[2][128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -98,6 +100,52 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
       }
     }
     any_nan = true;  // computed values: take the explicit NaN test below
+  } else if (PRE == 4) {
+    // RoPE backward of the attention gradients, quantised as the fused d(qkv) [rows, W] they merge into (grad_output of the
+    // q|k|v projection): x = dq [rows, nq*128], aux16 = dk, e0 = dv [rows, nk*128], aux32 / e1 = cos / sin [seq, 64] fp32,
+    // i0 = nq, i1 = nk, i2 = seq; head_dim 128.  Same expressions and bf16 rounding as rope_qkv_kernel<1> (mi_fused.hip), so
+    // the result equals mi_rope_qkv(backward) + mi_mxfp8_quantize bit for bit; the bf16 d(qkv) is never written.
+    constexpr int HD = 128, HALF = 64;
+    const int nq = i0, nk = i1, seq = i2;
+    const int hd = c0 / HD, within = c0 % HD;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[i][j] = 0.0f;
+      if (!active) continue;
+      const int64_t r = r0 + i;
+      if (hd < nq + nk) {
+        const uint16_t* src = hd < nq ? x + (r * nq + hd) * HD : aux16 + (r * nk + (hd - nq)) * HD;
+        const bool upper = within >= HALF;
+        const int cc = upper ? within - HALF : within;
+        const v4i a = *reinterpret_cast<const v4i*>(src + cc), b = *reinterpret_cast<const v4i*>(src + HALF + cc);
+        const int pos = (int)(r % seq);
+        float c[8], sn[8];
+        *reinterpret_cast<v4f*>(c) = *reinterpret_cast<const v4f*>(aux32 + (int64_t)pos * HALF + cc);
+        *reinterpret_cast<v4f*>(c + 4) = *reinterpret_cast<const v4f*>(aux32 + (int64_t)pos * HALF + cc + 4);
+        *reinterpret_cast<v4f*>(sn) = *reinterpret_cast<const v4f*>(e1 + (int64_t)pos * HALF + cc);
+        *reinterpret_cast<v4f*>(sn + 4) = *reinterpret_cast<const v4f*>(e1 + (int64_t)pos * HALF + cc + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const u32 wa = (u32)a[j], wb = (u32)b[j];
+          const float x1l = __uint_as_float(wa << 16), x1h = __uint_as_float(wa & 0xFFFF0000u);
+          const float x2l = __uint_as_float(wb << 16), x2h = __uint_as_float(wb & 0xFFFF0000u);
+          const float cl = c[2 * j], ch = c[2 * j + 1], sl = -1.0f * sn[2 * j], sh = -1.0f * sn[2 * j + 1];
+          const float ol = upper ? x2l * cl + x1l * sl : x1l * cl - x2l * sl;
+          const float oh = upper ? x2h * ch + x1h * sh : x1h * ch - x2h * sh;
+          f[i][2 * j] = __uint_as_float(float_to_bf16_bits(ol) << 16);
+          f[i][2 * j + 1] = __uint_as_float(float_to_bf16_bits(oh) << 16);
+        }
+      } else {
+        const v4i a = *reinterpret_cast<const v4i*>(e0 + r * (int64_t)(nk * HD) + (c0 - (nq + nk) * HD));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f[i][2 * j] = __uint_as_float((u32)a[j] << 16);
+          f[i][2 * j + 1] = __uint_as_float((u32)a[j] & 0xFFFF0000u);
+        }
+      }
+    }
+    any_nan = true;
   } else {
     const int F = PRE == 2 ? cols : cols / 2;
     const bool up_half = (PRE == 3) && (c0 >= F);
@@ -243,18 +291,19 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
 
 template <int FMT, int PRE>
 static int launch_mx(const void* x, const void* aux16, const float* aux32, void* y_row, void* s_row, void* y_colT, void* s_colT,
-                     float* colsum, int64_t rows, int64_t cols, hipStream_t st, int64_t ld_rows = 0) {
+                     float* colsum, int64_t rows, int64_t cols, hipStream_t st, int64_t ld_rows = 0, const void* e0 = nullptr,
+                     const float* e1 = nullptr, int i0 = 0, int i1 = 0, int i2 = 0) {
   const int ldr = (int)(ld_rows > 0 ? ld_rows : rows);
   const int tiles_r = (int)((rows + 127) / 128), tiles_c = (int)((cols + 127) / 128);
   dim3 grid((unsigned)(tiles_r * tiles_c)), block(256);
   const uint16_t *xp = (const uint16_t*)x, *ap = (const uint16_t*)aux16;
   uint8_t *yr = (uint8_t*)y_row, *sr = (uint8_t*)s_row, *yc = (uint8_t*)y_colT, *sc = (uint8_t*)s_colT;
   if (y_row && y_colT)
-    hipLaunchKernelGGL((mxfp8_quant_kernel<FMT, true, true, PRE>), grid, block, 0, st, xp, ap, aux32, yr, sr, yc, sc, colsum, (int)rows, (int)cols, tiles_c, ldr);
+    hipLaunchKernelGGL((mxfp8_quant_kernel<FMT, true, true, PRE>), grid, block, 0, st, xp, ap, aux32, yr, sr, yc, sc, colsum, (int)rows, (int)cols, tiles_c, ldr, (const uint16_t*)e0, e1, i0, i1, i2);
   else if (y_row)
-    hipLaunchKernelGGL((mxfp8_quant_kernel<FMT, true, false, PRE>), grid, block, 0, st, xp, ap, aux32, yr, sr, yc, sc, colsum, (int)rows, (int)cols, tiles_c, ldr);
+    hipLaunchKernelGGL((mxfp8_quant_kernel<FMT, true, false, PRE>), grid, block, 0, st, xp, ap, aux32, yr, sr, yc, sc, colsum, (int)rows, (int)cols, tiles_c, ldr, (const uint16_t*)e0, e1, i0, i1, i2);
   else
-    hipLaunchKernelGGL((mxfp8_quant_kernel<FMT, false, true, PRE>), grid, block, 0, st, xp, ap, aux32, yr, sr, yc, sc, colsum, (int)rows, (int)cols, tiles_c, ldr);
+    hipLaunchKernelGGL((mxfp8_quant_kernel<FMT, false, true, PRE>), grid, block, 0, st, xp, ap, aux32, yr, sr, yc, sc, colsum, (int)rows, (int)cols, tiles_c, ldr, (const uint16_t*)e0, e1, i0, i1, i2);
   MI_CHECK_LAUNCH("mi_mxfp8_quantize launch");
   return MI_OK;
 }
@@ -323,4 +372,22 @@ extern "C" int mi_mxfp8_dswiglu_quantize(const void* h_bf16, const void* dact_bf
   MI_CHECK_ARG(dact_bf16 && ((uintptr_t)dact_bf16 % 16) == 0, "mi_mxfp8_dswiglu_quantize: dact missing or misaligned");
   if (rows == 0 || F == 0) return MI_OK;
   return MI_MX_DISPATCH(3, h_bf16, dact_bf16, nullptr, colsum, rows, 2 * F);
+}
+
+extern "C" int mi_mxfp8_rope_bwd_quantize(const void* dq_bf16, const void* dk_bf16, const void* dv_bf16, const float* cos_tab,
+                                          const float* sin_tab, void* y_row, void* s_row, void* y_colT, void* s_colT, int64_t rows,
+                                          int64_t seq, int n_q_heads, int n_kv_heads, int head_dim, int fmt, void* stream) {
+  MI_CHECK_ARG(head_dim == 128, "mi_mxfp8_rope_bwd_quantize: head_dim %d not supported (128)", head_dim);
+  MI_CHECK_ARG(n_q_heads >= 1 && n_kv_heads >= 1 && seq >= 1, "mi_mxfp8_rope_bwd_quantize: bad head counts / seq");
+  const int64_t W = (int64_t)(n_q_heads + 2 * n_kv_heads) * head_dim;
+  int rc = mx_common_check("mi_mxfp8_rope_bwd_quantize", dq_bf16, y_row, s_row, y_colT, s_colT, rows, W, fmt);
+  if (rc != MI_OK) return rc;
+  MI_CHECK_ARG(dk_bf16 && dv_bf16 && cos_tab && sin_tab && ((uintptr_t)dk_bf16 % 16) == 0 && ((uintptr_t)dv_bf16 % 16) == 0 &&
+                   ((uintptr_t)cos_tab % 16) == 0 && ((uintptr_t)sin_tab % 16) == 0, "mi_mxfp8_rope_bwd_quantize: null or misaligned input");
+  if (rows == 0) return MI_OK;
+  return (fmt == MI_FMT_E4M3
+              ? mi::launch_mx<MI_FMT_E4M3, 4>(dq_bf16, dk_bf16, cos_tab, y_row, s_row, y_colT, s_colT, nullptr, rows, W, (hipStream_t)stream,
+                                              0, dv_bf16, sin_tab, n_q_heads, n_kv_heads, (int)seq)
+              : mi::launch_mx<MI_FMT_E5M2, 4>(dq_bf16, dk_bf16, cos_tab, y_row, s_row, y_colT, s_colT, nullptr, rows, W, (hipStream_t)stream,
+                                              0, dv_bf16, sin_tab, n_q_heads, n_kv_heads, (int)seq));
 }

@@ -33,14 +33,14 @@ class _CEFn(torch.autograd.Function):
         gscale = (dloss.to(torch.float32) / n_valid).reshape(1).contiguous()
         st = torch.cuda.current_stream().cuda_stream
         h = ctx.handoff
-        if h is not None and h.offered() and T % 8 == 0:
+        if h is not None and h.offered() and not h.mx and T % 8 == 0:
             y = torch.empty((T, V), dtype=torch.uint8, device=logits2d.device) if h.want_y else None
             yt = torch.empty((V, T), dtype=torch.uint8, device=logits2d.device) if h.want_t else None
             _lib.check(_lib.load().mi_ce_backward_cast(logits2d.data_ptr(), labels1d.data_ptr(), lse.data_ptr(), gscale.data_ptr(),
                                                        None if y is None else y.data_ptr(), None if yt is None else yt.data_ptr(),
                                                        h.scale.data_ptr(), h.amax.data_ptr(), T, V, h.fmt, st), "mi_ce_backward_cast")
             d = torch.empty_like(logits2d)  # placeholder: never written, never read (the lm_head's backward takes the FP8 copies)
-            h.put(y, yt, d)
+            h.put((y, yt), d)
             return d, None, None
         d = torch.empty_like(logits2d)
         _lib.check(_lib.load().mi_ce_backward(logits2d.data_ptr(), labels1d.data_ptr(), lse.data_ptr(), gscale.data_ptr(),

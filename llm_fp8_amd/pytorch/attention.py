@@ -100,11 +100,14 @@ class _RoPESplitFn(torch.autograd.Function):
         B, S, n_q, n_kv, d = ctx.meta
         T = B * S
         h = ctx.handoff
-        if h is not None and h.offered() and d == 128 and T % 8 == 0:
-            g8, g8t = ops.rope_qkv_backward_cast(dq.reshape(T, n_q * d), dk.reshape(T, n_kv * d), dv.reshape(T, n_kv * d), cos, sin,
-                                                 n_q, n_kv, d, S, h.scale, h.amax, h.fmt, want_y=h.want_y, want_t=h.want_t)
+        if h is not None and h.offered() and d == 128 and T % (32 if h.mx else 8) == 0:
+            args = (dq.reshape(T, n_q * d), dk.reshape(T, n_kv * d), dv.reshape(T, n_kv * d), cos, sin, n_q, n_kv, d, S)
+            if h.mx:
+                fp8 = ops.mxfp8_rope_bwd_quantize(*args, h.fmt, rowwise=h.want_y, colwise=h.want_t)
+            else:
+                fp8 = ops.rope_qkv_backward_cast(*args, h.scale, h.amax, h.fmt, want_y=h.want_y, want_t=h.want_t)
             g = torch.empty((B, S, (n_q + 2 * n_kv) * d), dtype=torch.bfloat16, device=dq.device)  # placeholder: never written
-            h.put(g8, g8t, g)
+            h.put(fp8, g)
             return g, None, None, None, None, None, None
         g = ops.rope_qkv_backward(dq.reshape(T, n_q * d), dk.reshape(T, n_kv * d), dv.reshape(T, n_kv * d), cos, sin,
                                   n_q, n_kv, d, S)
@@ -232,7 +235,7 @@ class MultiheadAttention(torch.nn.Module):
             q, k, v = _RoPESplitFn.apply(qkv, cos, sin, self.h, self.g, self.d, handoff)
             return self.proj(self.core_attention(q, k, v, attention_mask))
         if handoff is not None:
-            handoff.scale = None  # not the fused rotary path: withdraw the offer, the projection quantises its own grad_output
+            handoff.withdraw()  # not the fused rotary path: the projection quantises its own grad_output
         q, k, v = torch.split(qkv, self.split, dim=-1)
         a, b = qkv.shape[0], qkv.shape[1]
         q = q.reshape(a, b, self.h, self.d)

@@ -42,20 +42,25 @@ class DyHandoff:
     returns an UNWRITTEN bf16 placeholder as the autograd gradient; the Linear's backward `take`s the copies and never reads
     the placeholder.  One object per forward call, private to the module that wires the two together: nothing else may sit
     between them in the graph.  `take` checks that the gradient it was handed is that placeholder and fails loudly otherwise."""
-    __slots__ = ("scale", "amax", "fmt", "want_y", "want_t", "fp8", "ptr")
+    __slots__ = ("scale", "amax", "fmt", "want_y", "want_t", "fp8", "ptr", "mx")
 
     def __init__(self):
         self.scale = self.amax = self.fmt = self.fp8 = self.ptr = None
-        self.want_y = self.want_t = False
+        self.want_y = self.want_t = self.mx = False
 
-    def offer(self, scale, amax, fmt, want_y, want_t):
-        self.scale, self.amax, self.fmt, self.want_y, self.want_t = scale, amax, fmt, want_y, want_t
+    def offer(self, scale, amax, fmt, want_y, want_t, mx: bool = False):
+        """Delayed scaling: (scale, amax slot, format); MXFP8 (`mx`): the format only, the producer `put`s the four tensors of
+        ops.mxfp8_quantize (rowwise data + scales, columnwise data + scales) instead of (y, yT)."""
+        self.scale, self.amax, self.fmt, self.want_y, self.want_t, self.mx = scale, amax, fmt, want_y, want_t, mx
+
+    def withdraw(self):
+        self.scale, self.mx = None, False
 
     def offered(self) -> bool:
-        return self.scale is not None and (self.want_y or self.want_t)
+        return (self.scale is not None or self.mx) and (self.want_y or self.want_t)
 
-    def put(self, g8, g8t, placeholder: torch.Tensor):
-        self.fp8, self.ptr = (g8, g8t), placeholder.untyped_storage().data_ptr()
+    def put(self, fp8: tuple, placeholder: torch.Tensor):
+        self.fp8, self.ptr = fp8, placeholder.untyped_storage().data_ptr()
 
     def take(self, dy: torch.Tensor):
         if dy.untyped_storage().data_ptr() != self.ptr:
@@ -222,6 +227,8 @@ class _FP8LinearFn(torch.autograd.Function):
                     spec.wcache[ck] = (w8, ws, wt8, wts)
             y = ops.gemm_mxfp8(x8, xs, w8, ws, spec.fmt_fwd, spec.fmt_fwd, bias=bias_bf16)
             ctx.saved_fp8 = (xt8, xts, wt8, wts, None)
+            if spec.dy_handoff is not None and bias is None and (need_wgrad or need_dgrad):
+                spec.dy_handoff.offer(None, None, spec.fmt_bwd, need_dgrad, need_wgrad, mx=True)
         else:
             mf, g = spec.meta_fwd, spec.g
             if ln_w is not None:
@@ -258,7 +265,9 @@ class _FP8LinearFn(torch.autograd.Function):
         ctx.saved_fp8 = None
         dx = dw = db_fused = None
         if spec.recipe.mxfp8():
-            if ctx.has_bias and ctx.bias_dtype in (torch.bfloat16, torch.float32):  # the bias gradient rides on the quantisation
+            if spec.dy_handoff is not None and spec.dy_handoff.fp8 is not None:
+                g8, gs, gt8, gts = spec.dy_handoff.take(dy)  # already quantised by the op that produced it (dy is a placeholder)
+            elif ctx.has_bias and ctx.bias_dtype in (torch.bfloat16, torch.float32):  # the bias gradient rides on the quantisation
                 g8, gs, gt8, gts, cs = ops.mxfp8_quantize(g2, spec.fmt_bwd, rowwise=ctx.need_dgrad, colwise=ctx.need_wgrad,
                                                           want_colsum=True)
                 db_fused = ops.colsum_finish(cs, ctx.bias_dtype)

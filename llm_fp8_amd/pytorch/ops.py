@@ -266,6 +266,31 @@ def rope_qkv_backward(dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, cos:
     return out
 
 
+def mxfp8_rope_bwd_quantize(dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n_q: int,
+                            n_kv: int, head_dim: int, seq: int, fmt: int, rowwise: bool = True, colwise: bool = True):
+    """rope_qkv_backward + mxfp8_quantize of its result in one launch (same four outputs); the bf16 d(qkv) is never written."""
+    _dev(dq, dk, dv, cos, sin)
+    dq, dk, dv = (t.contiguous() for t in (dq, dk, dv))
+    T, W = dq.shape[0], (n_q + 2 * n_kv) * head_dim
+    y_row = s_row = y_colT = s_colT = None
+    if rowwise:
+        y_row = torch.empty((T, W), dtype=torch.uint8, device=dq.device)
+        s_row = torch.empty((W // 32, T), dtype=torch.uint8, device=dq.device)
+    if colwise:
+        y_colT = torch.empty((W, T), dtype=torch.uint8, device=dq.device)
+        s_colT = torch.empty((T // 32, W), dtype=torch.uint8, device=dq.device)
+    args = (dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), cos.data_ptr(), sin.data_ptr(), _ptr(y_row), _ptr(s_row), _ptr(y_colT),
+            _ptr(s_colT), T, seq, n_q, n_kv, head_dim, fmt, _stream())
+    t = KernelTimer.active
+    if t is None:
+        rc = _lib.load().mi_mxfp8_rope_bwd_quantize(*args)
+    else:
+        with t.span("mxfp8_quantize", f"rope {T}x{W}", float(T * W), float(T * W * (2 + (1 + 1 / 32) * (int(rowwise) + int(colwise))))):
+            rc = _lib.load().mi_mxfp8_rope_bwd_quantize(*args)
+    _lib.check(rc, "mi_mxfp8_rope_bwd_quantize")
+    return y_row, s_row, y_colT, s_colT
+
+
 def embedding_grad_add_(grad: torch.Tensor, dy: torch.Tensor, ids: torch.Tensor, alpha: float = 1.0, padding_idx: int = -1) -> None:
     """grad [V, H] bf16 += alpha * scatter-sum of dy [T, H] bf16 rows by ids [T] (int64), in place, deterministic."""
     _dev(grad, dy, ids)

@@ -463,6 +463,27 @@ def test_embedding_grad_add_in_place(ops, dev):
     assert untouched.sum() > 100 and torch.equal(outs[0][untouched].view(torch.int16), grad0[untouched].view(torch.int16))
 
 
+@pytest.mark.parametrize("fmt", [O.E5M2, O.E4M3])
+@pytest.mark.parametrize("shape", [(2, 128, 24, 8), (1, 96, 4, 2)])
+def test_mxfp8_rope_backward_quantize_is_bitwise_the_two_kernel_sequence(ops, dev, fmt, shape):
+    """mi_mxfp8_rope_bwd_quantize == mi_rope_qkv(backward) + mi_mxfp8_quantize: data and E8M0 scales, both orientations."""
+    B, S, nq, nkv = shape
+    D, T = 128, shape[0] * shape[1]
+    g = torch.Generator().manual_seed(S * 3 + nq)
+    dq = (torch.randn(T, nq * D, generator=g) * 0.3).to(torch.bfloat16).to(dev)
+    dk = (torch.randn(T, nkv * D, generator=g) * 30.0).to(torch.bfloat16).to(dev)
+    dv = (torch.randn(T, nkv * D, generator=g) * 1e-3).to(torch.bfloat16).to(dev)
+    dq[1, 5] = float("nan")
+    ang = torch.outer(torch.arange(S, dtype=torch.float32), 1.0 / (10000.0 ** (torch.arange(0, D, 2, dtype=torch.float32) / D)))
+    cos, sin = torch.cos(ang).contiguous().to(dev), torch.sin(ang).contiguous().to(dev)
+    ref = ops.mxfp8_quantize(ops.rope_qkv_backward(dq, dk, dv, cos, sin, nq, nkv, D, S), fmt)
+    got = ops.mxfp8_rope_bwd_quantize(dq, dk, dv, cos, sin, nq, nkv, D, S, fmt)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    row_only = ops.mxfp8_rope_bwd_quantize(dq, dk, dv, cos, sin, nq, nkv, D, S, fmt, colwise=False)
+    assert row_only[2] is None and torch.equal(row_only[0], ref[0]) and torch.equal(row_only[1], ref[1])
+
+
 # ----------------------------------------------------------------------------------------- K9 RMSNorm -> FP8
 @pytest.mark.parametrize("shape", [(8, 512), (137, 1024), (8192, 3072), (3, 8192), (64, 4104)])
 def test_add_rmsnorm_stats_matches_add_then_stats(ops, dev, shape):

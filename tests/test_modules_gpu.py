@@ -544,8 +544,9 @@ def test_grad_output_handoffs_are_bitwise_the_unfused_path(te, dev, scenario, mo
         else:
             monkeypatch.delenv("LLM_FP8_AMD_NO_DY_HANDOFF", raising=False)
         calls = {"rope": 0}
-        orig = _ops.rope_qkv_backward_cast
-        monkeypatch.setattr(_ops, "rope_qkv_backward_cast", lambda *a, **k: (calls.__setitem__("rope", calls["rope"] + 1), orig(*a, **k))[1])
+        name = "mxfp8_rope_bwd_quantize" if scenario == "mxfp8" else "rope_qkv_backward_cast"
+        orig = getattr(_ops, name)
+        monkeypatch.setattr(_ops, name, lambda *a, **k: (calls.__setitem__("rope", calls["rope"] + 1), orig(*a, **k))[1])
         cfg = train.TrainingConfig(model_name="llama-3.2-3b", batch_size=2, max_seq_length=128, mixed_precision="fp8",
                                    fp8_scenario=scenario, use_te=True, sharding_mode="none", num_hidden_layers=2, vocab_size=2048,
                                    learning_rate=1e-3, num_warmup_steps=0)
@@ -558,7 +559,7 @@ def test_grad_output_handoffs_are_bitwise_the_unfused_path(te, dev, scenario, mo
         losses = [train.train_step(model, train.synthetic_batch(cfg, 2048, device, gen), opt, sched, cfg).item() for _ in range(3)]
         hist = torch.cat([a.hist[:, :a.used].reshape(-1) for a in G._arenas.values()]).clone()
         flat = torch.cat([p.detach().reshape(-1).view(torch.int16) for p in model.parameters()]).clone()
-        monkeypatch.setattr(_ops, "rope_qkv_backward_cast", orig)
+        monkeypatch.setattr(_ops, name, orig)
         return losses, hist, flat, calls["rope"]
 
     try:
@@ -566,8 +567,8 @@ def test_grad_output_handoffs_are_bitwise_the_unfused_path(te, dev, scenario, mo
         l0, h0, w0, n0 = run(True)
     finally:
         G.reset()
-    # delayed-scaling attention takes the fused RoPE route (head_dim 128); under MXFP8 recipes only the lm_head hand-off is live
-    assert n0 == 0 and (n1 == 6 if scenario == "default" else n1 == 0), (n1, n0)
+    # 2 layers x 3 steps through the fused RoPE route (head_dim 128), in its delayed-scaling or its MXFP8 form
+    assert n0 == 0 and n1 == 6, (n1, n0)
     assert l1 == l0, (l1, l0)
     assert torch.equal(h1, h0) and torch.equal(w1, w0)
 
