@@ -216,8 +216,13 @@ class GradArenaDP(torch.nn.Module):
         if self.world == 1 and not _FORCE_COLLECTIVES:
             return
         flat = self.arenas[b.arena][b.start:b.end]
-        op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
-        self._works.append((dist.all_reduce(flat, op=op, group=self.group, async_op=True), flat))
+        if self._avg_in_collective:
+            try:
+                self._works.append((dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True), flat, False))
+                return
+            except (RuntimeError, ValueError):  # a backend build without AVG for this dtype: SUM, then scale (as with gloo)
+                self._avg_in_collective = False
+        self._works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat, True))
 
     def _finalize(self):
         """End of a backward pass (autograd engine callback): reduce what is still open, then make the compute stream wait
@@ -227,9 +232,9 @@ class GradArenaDP(torch.nn.Module):
                 for b in self.buckets:
                     if 0 < b.pending < len(b.params):  # same graph on every rank, so every rank closes the same buckets
                         self._close_partial(b)
-                for w, flat in self._works:
+                for w, flat, summed in self._works:
                     w.wait()
-                    if not self._avg_in_collective:
+                    if summed:
                         flat.mul_(1.0 / self.world)
                 if self._sparse:
                     self._reduce_sparse()
