@@ -210,9 +210,13 @@ def setup_distributed():
         if backend == "nccl":
             # RCCL's kernels on a high-priority stream: a bucket's all-reduce gets CUs as the GEMM's workgroups drain
             # instead of queueing behind the whole backward pass
-            opts = dist.ProcessGroupNCCL.Options()
-            opts.is_high_priority_stream = True
-            kw = {"pg_options": opts, "device_id": device}
+            kw = {"device_id": device}
+            try:
+                opts = dist.ProcessGroupNCCL.Options()
+                opts.is_high_priority_stream = True
+                kw["pg_options"] = opts
+            except (AttributeError, TypeError):  # a torch build without the options object: default-priority streams
+                pass
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, local, world, device
 
