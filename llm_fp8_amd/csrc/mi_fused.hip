@@ -176,7 +176,9 @@ __global__ __launch_bounds__(256) void rope_bwd_cast_kernel(const uint16_t* __re
     __syncthreads();
     if (tid == 0) {
       const float m = fmaxf(fmaxf(s_amax[0], s_amax[1]), fmaxf(s_amax[2], s_amax[3]));
-      if (m > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(amax_out), __float_as_uint(m));
+      // only a workgroup that would raise the value goes to the atomic unit: same-address atomics are served one at a time and a
+      // wave cannot retire before its atomic has returned (thousands of workgroups per launch)
+      if (m > 0.0f && m > __builtin_nontemporal_load(amax_out)) atomicMax(reinterpret_cast<unsigned int*>(amax_out), __float_as_uint(m));
     }
   }
 }
@@ -304,7 +306,9 @@ __global__ __launch_bounds__(256) void swiglu_cast_kernel(const uint16_t* __rest
     __syncthreads();
     if (tid == 0) {
       float m = fmaxf(fmaxf(s_amax[0], s_amax[1]), fmaxf(s_amax[2], s_amax[3]));
-      if (m > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(amax_out), __float_as_uint(m));
+      // only a workgroup that would raise the value goes to the atomic unit: same-address atomics are served one at a time and a
+      // wave cannot retire before its atomic has returned (thousands of workgroups per launch)
+      if (m > 0.0f && m > __builtin_nontemporal_load(amax_out)) atomicMax(reinterpret_cast<unsigned int*>(amax_out), __float_as_uint(m));
     }
   }
 }
@@ -417,7 +421,9 @@ __global__ __launch_bounds__(256) void norm_cast_kernel(const uint16_t* __restri
     __syncthreads();
     if (tid == 0) {
       float m = fmaxf(fmaxf(s_amax[0], s_amax[1]), fmaxf(s_amax[2], s_amax[3]));
-      if (m > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(amax_out), __float_as_uint(m));
+      // only a workgroup that would raise the value goes to the atomic unit: same-address atomics are served one at a time and a
+      // wave cannot retire before its atomic has returned (thousands of workgroups per launch)
+      if (m > 0.0f && m > __builtin_nontemporal_load(amax_out)) atomicMax(reinterpret_cast<unsigned int*>(amax_out), __float_as_uint(m));
     }
   }
 }
@@ -671,7 +677,9 @@ __global__ __launch_bounds__(256) void ce_bwd_cast_kernel(const uint16_t* __rest
     __syncthreads();
     if (tid == 0) {
       const float m = fmaxf(fmaxf(s_amax[0], s_amax[1]), fmaxf(s_amax[2], s_amax[3]));
-      if (m > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(amax_out), __float_as_uint(m));
+      // only a workgroup that would raise the value goes to the atomic unit: same-address atomics are served one at a time and a
+      // wave cannot retire before its atomic has returned (thousands of workgroups per launch)
+      if (m > 0.0f && m > __builtin_nontemporal_load(amax_out)) atomicMax(reinterpret_cast<unsigned int*>(amax_out), __float_as_uint(m));
     }
   }
 }
