@@ -74,6 +74,9 @@ int mi_cast_amax_colsum(const void* x_bf16, void* y_fp8, void* yT_fp8, const flo
 /* out[c] = sum_p partial[p, c]; out bf16 (MI_OUT_BF16) or fp32 (MI_OUT_F32).  Second stage of every partial column sum
  * the library emits (mi_cast_amax_colsum, mi_dswiglu_cast, mi_mxfp8_dswiglu_quantize, mi_rmsnorm_bwd). */
 int mi_colsum_finish(const float* partial, int64_t P, int64_t C, void* out, int out_dtype, void* stream);
+/* Up to 4 mi_colsum_finish in one launch (host arrays of length n; same arithmetic and summation order per output). */
+int mi_colsum_finish_multi(const void* const* partials, const int64_t* P, const int64_t* C, void* const* outs,
+                           const int* out_dtypes, int n, void* stream);
 
 /*
  * K3  amax-history roll + scale update for S slots in ONE launch

@@ -48,6 +48,7 @@ SIGNATURES = {
     "mi_add_rmsnorm_stats": [_p, _p, _p, _p, _c_i64, _c_i64, ctypes.c_float, _p],
     "mi_cast_amax_colsum": [_p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _p],
     "mi_colsum_finish": [_p, _c_i64, _c_i64, _p, _c_int, _p],
+    "mi_colsum_finish_multi": [_p, _p, _p, _p, _p, _c_int, _p],
     "mi_gemm_workspace_bytes": [],
     "mi_gemm_set_workspace": [_p, _c_i64],
     "mi_attn_fwd": [_p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_i64, ctypes.c_float,

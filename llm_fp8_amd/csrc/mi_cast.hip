@@ -146,12 +146,12 @@ static int cast_num_cus() {
 }
 
 // second stage of every [P, C] fp32 partial column sum (cast, dSwiGLU, RMSNorm backward): out[c] = sum_p part[p, c]
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int P, int C, void* __restrict__ out,
-                                                            int out_bf16) {
+__device__ __forceinline__ void colsum_finish_block(const float* __restrict__ part, int P, int C, void* __restrict__ out,
+                                                    int out_bf16, int block) {
   // 32 columns x 8 row-groups per workgroup: 128-byte row segments, 8 independent accumulation chains per column
   __shared__ float s_acc[8][32];
   const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cx;
+  const int c = block * 32 + cx;
   float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
   if (c < C) {
     int p = py;
@@ -172,6 +172,28 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
     if (out_bf16) reinterpret_cast<uint16_t*>(out)[c] = (uint16_t)float_to_bf16_bits(a);
     else reinterpret_cast<float*>(out)[c] = a;
   }
+}
+
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int P, int C, void* __restrict__ out,
+                                                            int out_bf16) {
+  colsum_finish_block(part, P, C, out, out_bf16, blockIdx.x);
+}
+
+// up to 4 finishes in one launch (a layer's bias gradients and its RMSNorm weight gradient: each is a 5-6 us kernel that is
+// all launch latency): the descriptors travel as kernel arguments, a workgroup finds its own by block range
+struct FinishDesc {
+  const float* part;
+  void* out;
+  int P, C, out_bf16, block_end;  // block_end: first block index AFTER this descriptor's range
+};
+struct FinishArgs {
+  FinishDesc d[4];
+};
+__global__ __launch_bounds__(256) void colsum_finish_multi_kernel(FinishArgs a, int n) {
+  int i = 0;
+  while (i + 1 < n && (int)blockIdx.x >= a.d[i].block_end) ++i;
+  const int first = i == 0 ? 0 : a.d[i - 1].block_end;
+  colsum_finish_block(a.d[i].part, a.d[i].P, a.d[i].C, a.d[i].out, a.d[i].out_bf16, (int)blockIdx.x - first);
 }
 
 template <int FMT>
@@ -250,5 +272,23 @@ extern "C" int mi_colsum_finish(const float* partial, int64_t P, int64_t C, void
   hipLaunchKernelGGL(mi::colsum_finish_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, (hipStream_t)stream, partial,
                      (int)P, (int)C, out, out_dtype == MI_OUT_BF16 ? 1 : 0);
   MI_CHECK_LAUNCH("mi_colsum_finish launch");
+  return MI_OK;
+}
+
+extern "C" int mi_colsum_finish_multi(const void* const* partials, const int64_t* P, const int64_t* C, void* const* outs,
+                                      const int* out_dtypes, int n, void* stream) {
+  MI_CHECK_ARG(partials && P && C && outs && out_dtypes && n >= 1 && n <= 4, "mi_colsum_finish_multi: 1 to 4 finishes per launch");
+  mi::FinishArgs a;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    MI_CHECK_ARG(partials[i] && outs[i], "mi_colsum_finish_multi: null pointer");
+    MI_CHECK_ARG(P[i] >= 1 && P[i] < (1 << 24) && C[i] >= 1 && C[i] < (1LL << 31), "mi_colsum_finish_multi: bad shape");
+    MI_CHECK_ARG(out_dtypes[i] == MI_OUT_BF16 || out_dtypes[i] == MI_OUT_F32, "mi_colsum_finish_multi: bad out_dtype %d", out_dtypes[i]);
+    blocks += (int)((C[i] + 31) / 32);
+    a.d[i] = {(const float*)partials[i], outs[i], (int)P[i], (int)C[i], out_dtypes[i] == MI_OUT_BF16 ? 1 : 0, blocks};
+  }
+  for (int i = n; i < 4; ++i) a.d[i] = {nullptr, nullptr, 0, 0, 0, blocks};
+  hipLaunchKernelGGL(mi::colsum_finish_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, n);
+  MI_CHECK_LAUNCH("mi_colsum_finish_multi launch");
   return MI_OK;
 }

@@ -408,7 +408,7 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
         g2 = _as_bf16_2d(dy)
         if ctx.dtypes[3] is not None:  # fc2 bias gradient rides on the quantisation of dy
             g8, gs, gt8, gts, cs2 = ops.mxfp8_quantize(g2, fmt_b, rowwise=True, colwise=ctx.need_w, want_colsum=True)
-            db2 = ops.colsum_finish(cs2, ctx.dtypes[3])
+            db2 = (cs2, ctx.dtypes[3])  # partial sums: finished with the layer's other column sums in _finish_backward
         else:
             g8, gs, gt8, gts = ops.mxfp8_quantize(g2, fmt_b, rowwise=True, colwise=ctx.need_w)
             db2 = None
@@ -417,7 +417,7 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
         want_b1 = ctx.dtypes[1] is not None
         dh8, dhs, dht8, dhts, colsum = ops.mxfp8_dswiglu_quantize(h, dact, fmt_b, rowwise=ctx.need_dgrad, colwise=ctx.need_w,
                                                                   want_colsum=want_b1)
-        db1 = ops.colsum_finish(colsum, ctx.dtypes[1]) if want_b1 else None
+        db1 = (colsum, ctx.dtypes[1]) if want_b1 else None
         dx = ops.gemm_mxfp8(dh8, dhs, w1t8, w1ts, fmt_b, fmt_f) if ctx.need_dgrad else None
         dw1 = ops.gemm_mxfp8(dht8, dhts, xt8, xts, fmt_b, fmt_f, out=_wgrad_out(ctx.w_refs[:1], xt8.shape[0])) if ctx.need_w else None
         return dx, dw1, db1, dw2, db2
@@ -435,7 +435,7 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
         # fc2 backward (GEMM index 1: bwd slot 2)
         if ctx.dtypes[3] is not None:  # fc2 bias gradient rides on the cast of dy
             g8, g8t, cs2 = ops.cast_amax(g2, mb.scale(2), mb.amax(2), fmt_b, want_t=ctx.need_w, want_colsum=True)
-            db2 = ops.colsum_finish(cs2, ctx.dtypes[3])
+            db2 = (cs2, ctx.dtypes[3])  # partial sums: finished with the layer's other column sums in _finish_backward
         else:
             g8, g8t = ops.cast_amax(g2, mb.scale(2), mb.amax(2), fmt_b, want_t=ctx.need_w)
             db2 = None
@@ -445,20 +445,28 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
         want_b1 = ctx.dtypes[1] is not None
         dh8, dh8t, colsum = ops.dswiglu_cast(h, dact, mb.scale(0), mb.amax(0), fmt_b, want_y=ctx.need_dgrad,
                                              want_t=ctx.need_w, want_colsum=want_b1)
-        db1 = ops.colsum_finish(colsum, ctx.dtypes[1]) if want_b1 else None
+        db1 = (colsum, ctx.dtypes[1]) if want_b1 else None
         dx = ops.gemm_fp8(dh8, w1_8t, mb.scale_inv(0), sinv[1], fmt_b, fmt_f) if ctx.need_dgrad else None
         dw1 = ops.gemm_fp8(dh8t, x8t, mb.scale_inv(0), sinv[0], fmt_b, fmt_f, out=_wgrad_out(ctx.w_refs[:1], x8t.shape[0])) if ctx.need_w else None
         return _FP8SwiGLUMLPFn._finish_backward(ctx, dx, dw1, db1, dw2, db2, dskip)
 
     @staticmethod
     def _finish_backward(ctx, dx, dw1, db1, dw2, db2, dskip=None):
+        """db1 / db2 arrive as (partial column sums, dtype): one launch finishes them together with the RMSNorm weight gradient."""
         spec = ctx.spec
         dln = None
         if ctx.norm is not None and dx is not None:
             xin, rstd, gam, ln_dtype = ctx.norm
             ctx.norm = None
-            dx, dln = ops.rmsnorm_bwd(dx, xin, rstd, gam, dres=_skip_2d(dskip, dx), dgamma_dtype=ln_dtype)
+            dx, dln = ops.rmsnorm_bwd(dx, xin, rstd, gam, dres=_skip_2d(dskip, dx), dgamma_dtype=ln_dtype, finish=False)
+            dln = (dln, ln_dtype)
             dskip = None
+        pend = [t for t in (db1, db2, dln) if t is not None]
+        if pend:
+            done = iter(ops.colsum_finish_multi(pend))
+            db1 = next(done) if db1 is not None else None
+            db2 = next(done) if db2 is not None else None
+            dln = next(done) if dln is not None else None
         if spec.trigger_bwd_update:
             FP8GlobalStateManager.reduce_and_update_fp8_tensors(forward=False)
         if dx is not None:

@@ -74,6 +74,31 @@ def colsum_finish(partial: torch.Tensor, dtype: torch.dtype = torch.bfloat16) ->
     return out
 
 
+def colsum_finish_multi(items):
+    """colsum_finish for a list of (partial [P, C] fp32, dtype) in as few launches as possible (4 per launch); same results."""
+    import ctypes
+    outs = [None] * len(items)
+    todo = []
+    for i, (partial, dtype) in enumerate(items):
+        _dev(partial)
+        assert partial.dtype == torch.float32 and partial.dim() == 2 and partial.is_contiguous()
+        if dtype not in (torch.bfloat16, torch.float32):
+            outs[i] = partial.sum(0).to(dtype)
+        else:
+            outs[i] = torch.empty(partial.shape[1], dtype=dtype, device=partial.device)
+            todo.append(i)
+    for k in range(0, len(todo), 4):
+        grp = todo[k:k + 4]
+        n = len(grp)
+        parts = (ctypes.c_void_p * n)(*[items[i][0].data_ptr() for i in grp])
+        Ps = (ctypes.c_int64 * n)(*[items[i][0].shape[0] for i in grp])
+        Cs = (ctypes.c_int64 * n)(*[items[i][0].shape[1] for i in grp])
+        os_ = (ctypes.c_void_p * n)(*[outs[i].data_ptr() for i in grp])
+        dts = (ctypes.c_int * n)(*[0 if items[i][1] == torch.bfloat16 else 1 for i in grp])
+        _lib.check(_lib.load().mi_colsum_finish_multi(parts, Ps, Cs, os_, dts, n, _stream()), "mi_colsum_finish_multi")
+    return outs
+
+
 def cast_amax(x: torch.Tensor, scale: torch.Tensor, amax: Optional[torch.Tensor], fmt: int,
               want_y: bool = True, want_t: bool = True,
               y: Optional[torch.Tensor] = None, yT: Optional[torch.Tensor] = None, want_colsum: bool = False):
@@ -412,7 +437,8 @@ def norm_cast(x: torch.Tensor, rstd: torch.Tensor, gamma: torch.Tensor, scale: t
 
 
 def rmsnorm_bwd(dy: torch.Tensor, x: torch.Tensor, rstd: torch.Tensor, gamma: torch.Tensor,
-                dres: Optional[torch.Tensor] = None, n_partials: int = 512, dgamma_dtype: torch.dtype = torch.float32):
+                dres: Optional[torch.Tensor] = None, n_partials: int = 512, dgamma_dtype: torch.dtype = torch.float32,
+                finish: bool = True):
     """K9 backward: (dx bf16 [R, C], dgamma [C] in `dgamma_dtype`).  dgamma is the fixed-order sum of per-block partials;
     `dres` (bf16 [R, C]) is added to dx (the gradient arriving over the residual connection)."""
     _dev(dy, x, rstd, gamma, dres)
@@ -424,7 +450,7 @@ def rmsnorm_bwd(dy: torch.Tensor, x: torch.Tensor, rstd: torch.Tensor, gamma: to
     rc = _lib.load().mi_rmsnorm_bwd(dy.data_ptr(), x.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), _ptr(dres), dx.data_ptr(),
                                     part.data_ptr(), n_partials, R, C, _stream())
     _lib.check(rc, "mi_rmsnorm_bwd")
-    return dx, colsum_finish(part, dgamma_dtype)
+    return (dx, colsum_finish(part, dgamma_dtype)) if finish else (dx, part)
 
 
 def _mx_alloc(R: int, C: int, dev, rowwise: bool, colwise: bool):

@@ -484,6 +484,17 @@ def test_mxfp8_rope_backward_quantize_is_bitwise_the_two_kernel_sequence(ops, de
     assert row_only[2] is None and torch.equal(row_only[0], ref[0]) and torch.equal(row_only[1], ref[1])
 
 
+def test_colsum_finish_multi_equals_single_finishes(ops, dev):
+    g = torch.Generator().manual_seed(5)
+    items = [(torch.randn(64, 3072, generator=g).to(dev), torch.bfloat16), (torch.randn(64, 16384, generator=g).to(dev), torch.bfloat16),
+             (torch.randn(512, 3072, generator=g).to(dev), torch.float32), (torch.randn(3, 40, generator=g).to(dev), torch.bfloat16),
+             (torch.randn(9, 33, generator=g).to(dev), torch.float32), (torch.randn(7, 64, generator=g).to(dev), torch.float16)]
+    multi = ops.colsum_finish_multi(items)
+    for (part, dt), got in zip(items, multi):
+        want = ops.colsum_finish(part, dt)
+        assert got.dtype == dt and torch.equal(got, want)
+
+
 # ----------------------------------------------------------------------------------------- K9 RMSNorm -> FP8
 @pytest.mark.parametrize("shape", [(8, 512), (137, 1024), (8192, 3072), (3, 8192), (64, 4104)])
 def test_add_rmsnorm_stats_matches_add_then_stats(ops, dev, shape):
