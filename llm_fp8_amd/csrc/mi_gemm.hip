@@ -31,6 +31,7 @@
 // reference path (te_llama.py:45-63,76-80; Appendix B shapes).
 #include "mi_common.h"
 #include <atomic>
+#include <cstdlib>
 #include <type_traits>
 
 namespace mi {
@@ -50,6 +51,17 @@ __device__ __forceinline__ v4f mfma_ba(const v8i& a, const v8i& b, v4f acc, int 
 template <int FA, int FB, int OPS>
 __device__ __forceinline__ v4f mfma_ba_sel(const v8i& a, const v8i& b, v4f acc, int sa, int sb) {
   return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(b, a, acc, FB, FA, 0, sb, OPS, sa);
+}
+
+// D = A.B + 0 written as inline asm with the accumulator TIED ("+v"): the hardware ignores the old value (src C is the inline
+// constant 0), but the register allocator sees the same read-modify-write as an accumulating MFMA and keeps the tile's
+// accumulators in place.  With the builtin and a zero C operand it stops accumulating in place around the tile loop, spills
+// the fresh accumulators and reloads them behind `s_waitcnt vmcnt(0)`.  Unit scales only (per-tensor path).
+template <int FA, int FB>
+__device__ __forceinline__ void mfma_ba_zero(const v8i& a, const v8i& b, v4f& acc, int unit) {
+  asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0] cbsz:%4 blgp:%5"
+               : "+v"(acc)
+               : "v"(b), "v"(a), "v"(unit), "n"(FB), "n"(FA));
 }
 
 __device__ __forceinline__ int swz_f(int row) { return ((row >> 1) & 3) << 1; }  // depends on row & 7 only
@@ -493,7 +505,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // then one lane publishes flags[v] = epoch).  A range may END inside a tile: that head part is computed LAST; the
 // workgroup then waits for flags[v + 1] == epoch (set long before, the neighbour produced it first thing), adds the
 // neighbour's partial accumulators and runs the normal epilogue.  Producers never wait, so there is no cycle.
-template <int FA, int FB, int ABL = 0, bool MX = false, bool BIAS = false, int MA1 = 4, int NB1 = 2, bool SK = false>
+template <int FA, int FB, int ABL = 0, bool MX = false, bool BIAS = false, int MA1 = 4, int NB1 = 2, bool SK = false, bool DEPI = true>
 __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
                                                       uint16_t* __restrict__ D, const float* __restrict__ sa_inv,
                                                       const float* __restrict__ sb_inv, int K, int lda, int ldb,
@@ -517,10 +529,23 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   constexpr bool PERM = MX;
   // behind the operand buffers: 6 KiB for the E8M0 scales (MX: 2 slots x {A, B} x 4 k-blocks x 256 rows, padded) and 4 KiB of
   // bias windows (BIAS: 2 slots x 8 waves x 256 B)
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes + ((MX || BIAS) ? 10240 : 0)];
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes + ((MX || BIAS) ? 10240 : 0) + (ABL == 9 ? 16384 : 0)];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
+  // ABL == 9 (diagnostic build, algo 22): waves 0 and 4 of workgroup 0 stamp s_memtime at the start of every MFMA segment and at
+  // the end of every phase into LDS (2 x 1024 stamps) and dump them to the u64 buffer passed as `bias` when the kernel ends
+  int stamp_idx = 0;
+  unsigned long long* const stamp_lds = reinterpret_cast<unsigned long long*>(lds + kLdsBytes + ((MX || BIAS) ? 10240 : 0)) + (wave >> 2) * 1024;
+  auto stamp = [&]() {
+    if (ABL == 9) {
+      if (blockIdx.x == 0 && (wave & 3) == 0 && stamp_idx < 1024) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (lane == 0) stamp_lds[stamp_idx] = t;
+        ++stamp_idx;
+      }
+    }
+  };
   const int ntiles = tiles_m * tiles_n;
   const int G = gridDim.x;
   const int bid = blockIdx.x;
@@ -613,6 +638,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
     tile_mn(ti, tm, tn);
     ra = tm * TBM;
     rb = tn * TBN;
+    if (ABL == 7) ra = rb = 0;  // timing ablation: every tile streams the panels of tile (0, 0) -> all operand reads hit L2
     oa = ra * lda;
     ob = rb * ldb;
   };
@@ -649,10 +675,12 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   stage_n<nA1>(rsA, a1_voff, oa_0 + kb0, buf0 + kOffA1, wave);
   stage_n<2>(rsA, a0_voff, oa_1 + kt_1 * BK, buf1 + kOffA0, wave);
   stage_n<2>(rsB, b0_voff, ob_1 + kt_1 * BK, buf1 + kOffB0, wave);
-  if (ABL == 3) {  // experiment: de-synchronise the CUs' epilogue bursts (odd workgroups start ~K/2 late)
-    if (bid & 1) {
-      for (int i = 0; i < (nk + 5) / 6; ++i) __builtin_amdgcn_s_sleep(127);
-    }
+  if (!SK && sk_U > 0) {
+    // Start stagger (sk_U = units of 512 cycles per class, 0 = off): the CUs of an XCD start in 4 classes a few microseconds
+    // apart, so their epilogue store bursts (128 KiB per CU and tile, all CUs at once = 32 MiB against ~6 TB/s of store
+    // bandwidth) no longer coincide: a burst that has to drain chip-wide holds the next K-tiles' loads behind it.
+    const int cls = (bid >> 3) & 3;
+    for (int i = 0; i < cls * sk_U; ++i) __builtin_amdgcn_s_sleep(8);
   }
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -673,19 +701,34 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   //   p1: nothing new     -> as loose as p0's successor allows            = W + EX
   //   p2: A0/B0(step+1)   -> EX + nB1 + nA1 + 2 younger                   = W + EX - 2
   //   p3: B1(step+1)      -> nA1 + 2 + 2 younger                          = W - nB1
-  // `after_epi` (uniform): first K-tile behind an epilogue, whose NST stores sit between the loads awaited in p0-p2 and the
-  // younger ones.  p3 awaits ops issued AFTER the stores (this K-tile's EX ops and B1), so it is never widened by NST: widened,
-  // it let the next step's block scales / bias window stay in flight past the reads of the following K-tile -- seen as
-  // run-to-run differences of the mxfp8 loss.
-#define MI_WAIT_SYNC(after_epi, PH)                                                                      \
-  {                                                                                                      \
-    constexpr int kAllow = (PH) == 0 ? W + EX - nA1 : (PH) == 1 ? W + EX : (PH) == 2 ? W + EX - 2 : W - nB1; \
-    if ((after_epi) && (PH) != 3) wait_vmcnt<kAllow + NST>(); /* p3 awaits B1 issued AFTER the stores */  \
-    else wait_vmcnt<kAllow>();                                                                           \
-  }                                                                                                      \
-  __builtin_amdgcn_s_barrier();                                                                          \
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
-  __builtin_amdgcn_sched_barrier(0);                                                                     \
+  // Epilogue, DISTRIBUTED (non-stream-K path): a finished tile is converted and stored in the load segments of the four phases
+  // of the NEXT tile's first K-tile (mode 1), a quarter per phase (epi_part: fragment rows [0, H) of a half in the phase whose
+  // MFMAs overwrite its first column block, rows [H, F) one phase later), always AFTER the phase's own LDS-DMA issues.  Why:
+  // vmcnt retires in order, so a wait for a load issued after a store also waits for that store's write-through acknowledge,
+  // and the CU's store path is slow (tools/probe_store.hip): with all 16 stores of a wave issued in one block the first wait
+  // behind them stalled for microseconds per tile (K sweep: 5.4 us per round of tiles, 10-13 % of the K = 3072 sites).
+  // Distributed, a store group has 4 phases to drain before a wait covers it, and the conversion VALU work runs beside the
+  // partner wave group's MFMAs.  (Two groups of 8 stores, in phases 0 and 2, were measured no better than the block epilogue.)
+  // Stores per phase: n0 = n1 = 4, n2 = n3 = MA1.  Ops allowed in flight at the four waits:
+  //   mode 0, flag = first K-tile behind a BLOCK epilogue (stream-K path, algo 46): p0-p2 + NST, p3 + 0 (awaits B1 issued after them)
+  //   mode 1, flag = a previous tile is stored in this K-tile:  + n0 | + n0+n1 | + n0+n1+n2 | + n0+n1+n2+n3
+  //           (every awaited load is older than the stores counted: p3's B1 was issued in p0 BEFORE the first store)
+  //   mode 2, flag = the K-tile behind such a mode-1 K-tile:  p0 awaits A1 issued in its p1, between the stores of n0 and n1:
+  //           + n1+n2+n3;  p1 the same;  p2 awaits B0 issued in its p3 before the stores of n3: + n3;  p3: + 0
+  // MX (no registers for the parked block): the halves leave whole in phases 0 and 2: n0 = 8, n1 = 0, n2 = 2 MA1, n3 = 0.
+#define MI_WAIT_SYNC(MODE_, flag, PH)                                                                              \
+  {                                                                                                                \
+    constexpr int kAllow = (PH) == 0 ? W + EX - nA1 : (PH) == 1 ? W + EX : (PH) == 2 ? W + EX - 2 : W - nB1;       \
+    constexpr int kS0 = MX ? 8 : 4, kS1 = MX ? 0 : 4, kS2 = MX ? 2 * MA1 : MA1, kS3 = MX ? 0 : MA1; /* stores per phase */ \
+    constexpr int kX = (MODE_) == 0 ? ((PH) != 3 ? NST : 0)                                                        \
+                     : (MODE_) == 1 ? ((PH) == 0 ? kS0 : (PH) == 1 ? kS0 + kS1 : (PH) == 2 ? kS0 + kS1 + kS2 : kS0 + kS1 + kS2 + kS3) \
+                                    : ((PH) <= 1 ? kS1 + kS2 + kS3 : (PH) == 2 ? kS3 : 0);                         \
+    if ((flag) && kX != 0) wait_vmcnt<kAllow + kX>();                                                              \
+    else wait_vmcnt<kAllow>();                                                                                     \
+  }                                                                                                                \
+  __builtin_amdgcn_s_barrier();                                                                                    \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
+  __builtin_amdgcn_sched_barrier(0);                                                                               \
   __builtin_amdgcn_s_setprio(1);
 #define MI_PIN(NI, NJ, EXPR)                                           \
   _Pragma("unroll") for (int i = 0; i < NI; ++i)                       \
@@ -700,12 +743,184 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
       default: return mfma_ba_sel<FA, FB, 3>(a_, b_, c_, sa_[0], sb_);
     }
   };
-  auto ktile = [&](uint8_t* cur, uint8_t* oth, bool after_epi, int slot) {
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int ecol = (fq & 1) * 16 + (fq >> 1) * 8;  // column of this lane's 8-wide piece after the permlane16 swap
+  const int d_voff = ((wr * (RA0 + RA1) + (PERM ? 4 : 1) * fr) * ldd + wc * (RB0 + RB1)) * 2;  // bytes, within the tile (half 0)
+  const int d_voff1 = (PERM && MA1 != 4) ? ((wr * (RA0 + RA1) + MA1 * fr) * ldd + wc * (RB0 + RB1)) * 2 : d_voff;  // half 1
+  auto tile_d_off = [&](int ti) -> int {  // uniform byte offset of tile ti's output
+    int tm, tn;
+    tile_mn(ti, tm, tn);
+    return (tm * TBM * ldd + tn * TBN) * 2;
+  };
+  // whole-line form (NB1 == 2): lane (m = fr, q = fq) of the first store of a fragment pair covers row m & 7, the second row
+  // 8 + (m & 7); lanes m >= 8 carry the second 32-column block of those rows
+  const int d_voff_line = ((wr * (RA0 + RA1) + (PERM ? 4 : 1) * (fr & 7)) * ldd + wc * (RB0 + RB1) + (fr >> 3) * RB0 + ecol) * 2;
+  const int d_voff_line1 = (PERM && MA1 != 4) ? ((wr * (RA0 + RA1) + MA1 * (fr & 7)) * ldd + wc * (RB0 + RB1) + (fr >> 3) * RB0 + ecol) * 2 : d_voff_line;
+  // convert + store the accumulators of row half a (both column blocks) of the tile whose output starts at byte d_tile; bias slot bslot.
+  // A fragment pair (a, i, b) gives, after the permlane16 swap, 16 rows x 64 B per store instruction: half-line segments,
+  // which one CU stores at 33 GB/s whatever the cache policy, against 72-118 GB/s for whole 128-B lines
+  // (tools/probe_store.hip).  With NB1 == 2 the two column blocks of a fragment row are therefore exchanged between lanes m and
+  // m ^ 8 (DPP row_ror:8): store 1 = rows 0-7 x 128 B, store 2 = rows 8-15 x 128 B.
+  // PART 0 / 1 = first / second phase of the half (phases 0, 1 for half 0; 2, 3 for half 1); PART 2 = the whole half at once.
+  // The column block that the first phase's MFMAs are about to overwrite (block 0 for half 0, block 1 for half 1) is packed
+  // for the second group of fragment rows and parked in `held` (8 registers) until the second phase, where it meets the other
+  // column block of the same rows: every phase issues the same number of stores (4 | 4 | MA1 | MA1), all whole-line.
+  constexpr bool EPI4 = !MX;  // MX: no registers left for `held` -> the halves leave whole, in phases 0 and 2
+  v4i held[2];
+  auto epi_part = [&](auto a_c, auto part_c, int d_tile, int bslot, bool zero) __attribute__((always_inline)) {
+    constexpr int a = decltype(a_c)::value, PART = decltype(part_c)::value;
+    constexpr int F = a == 0 ? 4 : MA1, H = F / 2;  // fragment rows of the half; rows [0, H) leave in part 0, [H, F) in part 1
+    constexpr int bf = a == 0 ? 0 : 1;              // the column block overwritten first
+    float bv[2][2][4];
+    if (BIAS) {
+      // This wave's own LDS-DMA data, landed long ago (covered by the vmcnt waits of the previous tile's K-tiles), so no wait is
+      // needed -- but hipcc puts `s_waitcnt vmcnt(0)` in front of a C++ read of LDS bytes that a dword LDS-DMA may have written
+      // (it cannot see the counted waits in the inline asm), which drained the whole prefetch pipeline at every use.  The reads
+      // are therefore inline asm too.
+      const unsigned bp = (unsigned)(size_t)LDS_PTR(bbuf + (bslot * 8 + wave) * 256 + fq * 8);
+      typedef unsigned int v2u_ __attribute__((ext_vector_type(2)));
+      v2u_ w[2][2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < (b == 0 ? 2 : NB1); ++j)
+          asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(w[b][j]) : "v"(bp), "n"((b * RB0 + j * 16) * 2));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < (b == 0 ? 2 : NB1); ++j) {
+          bv[b][j][0] = __uint_as_float(w[b][j].x << 16);
+          bv[b][j][1] = __uint_as_float(w[b][j].x & 0xFFFF0000u);
+          bv[b][j][2] = __uint_as_float(w[b][j].y << 16);
+          bv[b][j][3] = __uint_as_float(w[b][j].y & 0xFFFF0000u);
+        }
+    }
+    auto zero_blk = [&](int i, int b) __attribute__((always_inline)) {
+      if (zero) {
+#pragma unroll
+        for (int j = 0; j < (b == 0 ? 2 : NB1); ++j) acc[a][i][b][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    // 16 B per lane of column block b, row (a, i, fr): 8 contiguous columns from ecol (two MFMA tiles, permlane16 swap), or for
+    // the single-tile block of the 192-column shapes (NB1 == 1, b == 1) 4 columns in .x/.y
+    auto pack_blk = [&](int i, int b) __attribute__((always_inline)) -> v4i {
+      if (b == 1 && NB1 == 1) {
+        v4f v0 = acc[a][i][1][0] * alpha;
+        if (BIAS) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v0[e] += bv[1][0][e];
+        }
+        return (v4i){(int)pack_bf16x2(v0[0], v0[1]), (int)pack_bf16x2(v0[2], v0[3]), 0, 0};
+      }
+      v4f v0 = acc[a][i][b][0] * alpha, v1 = acc[a][i][b][1] * alpha;
+      if (BIAS) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v0[e] += bv[b][0][e];
+          v1[e] += bv[b][1][e];
+        }
+      }
+      u32 p0x = pack_bf16x2(v0[0], v0[1]), p0y = pack_bf16x2(v0[2], v0[3]);
+      u32 p1x = pack_bf16x2(v1[0], v1[1]), p1y = pack_bf16x2(v1[2], v1[3]);
+      auto sx = __builtin_amdgcn_permlane16_swap(p0x, p1x, false, false);
+      auto sy = __builtin_amdgcn_permlane16_swap(p0y, p1y, false, false);
+      return (v4i){(int)sx[0], (int)sy[0], (int)sx[1], (int)sy[1]};
+    };
+    // hipcc (ROCm 7.2) lets the next VALU overwrite the data registers of a 16-byte store (SGPR-offset form) with no wait
+    // state: lanes 12-15 of every 16-lane row then stored the NEXT block's unconverted fp32 (seen on MI355X).  Every store is
+    // followed by `s_nop 1` that keeps its registers live across the required wait states.
+    // aux 16 = sc1: write-through, the line is not kept in this XCD's L2.  A tile's 128 KiB of output per CU (4 MiB per XCD =
+    // its whole L2) would otherwise evict the A/B panels the next tile streams (measured -5..6 % kernel time at K = 2048-4096).
+    auto store_row = [&](int i, const v4i& o0, const v4i& o1) __attribute__((always_inline)) {  // o0 / o1 = column block 0 / 1
+      const int rowoff = d_tile + ((a * RA0 + (PERM ? i : i * 16)) * ldd) * 2;
+      if (ABL == 1) {
+        asm volatile("" ::"v"(o0), "v"(o1));
+      } else if (NB1 == 2 && ABL != 11) {
+        const bool lo = fr < 8;
+        v4i x, y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int t = lo ? o1[e] : o0[e];                                          // what lane m ^ 8 needs
+          const int r = __builtin_amdgcn_update_dpp(0, t, 0x128, 0xF, 0xF, false);  // row_ror:8 = lane m ^ 8 of the 16-lane row
+          x[e] = lo ? o0[e] : r;
+          y[e] = lo ? r : o1[e];
+        }
+        const int dvo = a == 0 ? d_voff_line : d_voff_line1;
+        constexpr int kRow8 = 8 * (PERM ? F : 1);
+        __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)x, rsD, dvo, rowoff, ABL == 4 ? 0 : 16);
+        asm volatile("s_nop 1" ::"v"(x) : "memory");
+        __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)y, rsD, dvo, rowoff + kRow8 * ldd * 2, ABL == 4 ? 0 : 16);
+        asm volatile("s_nop 1" ::"v"(y) : "memory");
+      } else {  // half-line stores: 192-column shapes (NB1 == 1: 64 B + 32 B per row), and ABL == 11 (A/B baseline)
+        const int dvo = a == 0 ? d_voff : d_voff1;
+        __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)o0, rsD, dvo + ecol * 2, rowoff, ABL == 4 ? 0 : 16);
+        asm volatile("s_nop 1" ::"v"(o0) : "memory");
+        if (NB1 == 2) {
+          __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)o1, rsD, dvo + ecol * 2, rowoff + RB0 * 2, ABL == 4 ? 0 : 16);
+        } else {
+          typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+          const v2u o2 = {(unsigned)o1[0], (unsigned)o1[1]};
+          __builtin_amdgcn_raw_buffer_store_b64(o2, rsD, dvo + fq * 8, rowoff + RB0 * 2, 16);
+        }
+        asm volatile("s_nop 1" ::"v"(o1) : "memory");
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < F; ++i) {
+      const bool first_rows = i < H;
+      if (PART == 2 || (PART == 0 && first_rows)) {  // both column blocks now
+        const v4i o0 = pack_blk(i, 0), o1 = pack_blk(i, 1);
+        store_row(i, o0, o1);
+        zero_blk(i, 0);
+        zero_blk(i, 1);
+      } else if (PART == 0) {  // park the block that is about to be overwritten
+        held[i - H] = pack_blk(i, bf);
+        zero_blk(i, bf);
+      } else if (!first_rows) {  // PART == 1: the parked block meets the other one
+        const v4i oo = pack_blk(i, 1 - bf);
+        if (bf == 0) store_row(i, held[i - H], oo);
+        else store_row(i, oo, held[i - H]);
+        zero_blk(i, 1 - bf);
+      }
+    }
+  };
+  using c0_t = std::integral_constant<int, 0>;
+  using c1_t = std::integral_constant<int, 1>;
+  using c2_t = std::integral_constant<int, 2>;
+  auto epilogue_block = [&](int ti, bool zero) __attribute__((always_inline)) {  // both halves at once (last tile of a workgroup; stream-K path)
+    const int d_tile = tile_d_off(ti);
+    epi_part(c0_t{}, c2_t{}, d_tile, ti & 1, zero);
+    epi_part(c1_t{}, c2_t{}, d_tile, ti & 1, zero);
+  };
+
+  // mode 0: plain K-tile (flag: behind a block epilogue); mode 1: first K-tile of a tile -- zero-C MFMAs, and when `flag` the
+  // quadrants of the previous tile (output offset d_prev, bias slot bslot_prev) leave in its load segments; mode 2: the K-tile
+  // behind a mode-1 K-tile (flag: that one carried stores).
+  auto ktile = [&](auto mode_c, uint8_t* cur, uint8_t* oth, bool flag, int slot, int d_prev, int bslot_prev) {
+    constexpr int MODE = decltype(mode_c)::value;
+    // (zero-C MFMAs in the first K-tile were tried: the allocator then stops accumulating in place, spills the fresh quadrants and
+    // reloads them behind `s_waitcnt vmcnt(0)`; the quadrants are zeroed by v_mov right after their stores instead)
+    constexpr bool ZC = MODE == 1 && !MX;  // first K-tile of a tile: accumulate onto zero (mfma_ba_zero), no v_mov zeroing
     const uint8_t* sc = sbuf + slot * kSSlot + sfq * kSK + sfr;  // A scales: + tile row of the fragment
     const uint8_t* scb = sc + kSOp;                              // B scales
     const int sa1 = oa_1 + kt_1 * BK, sb1 = ob_1 + kt_1 * BK;
     const int sa2 = oa_2 + kt_2 * BK, sb2 = ob_2 + kt_2 * BK;
     // ---- phase 0: C[0][*][0][*]
+    // mode 1: the LDS-DMA issues and the previous tile's quadrant come FIRST, the fragment reads after them: the fragments are
+    // then not live across the conversion (the kernel sits at the 256-VGPR limit), at the price of their LDS latency once per tile
+    if (MODE == 1) {
+      stage_scales(slot ^ 1, kt_1, ra_1, rb_1);
+      stage_bias(ti_1 & 1, rb_1);
+      stage_n<nB1>(rsB, b1_voff, sb1, oth + kOffB1, wave);
+      if (flag) {
+        if (EPI4) epi_part(c0_t{}, c0_t{}, d_prev, bslot_prev, !ZC);
+        else epi_part(c0_t{}, c2_t{}, d_prev, bslot_prev, !ZC);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) b0f[j] = read_frag(cur + kOffB0, wc * 2 + j, lane);
 #pragma unroll
@@ -731,128 +946,90 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
         }
       }
     }
-    stage_scales(slot ^ 1, kt_1, ra_1, rb_1);
-    stage_bias(ti_1 & 1, rb_1);
-    stage_n<nB1>(rsB, b1_voff, sb1, oth + kOffB1, wave);
-    MI_WAIT_SYNC(after_epi, 0)
+    if (MODE != 1) {
+      stage_scales(slot ^ 1, kt_1, ra_1, rb_1);
+      stage_bias(ti_1 & 1, rb_1);
+      stage_n<nB1>(rsB, b1_voff, sb1, oth + kOffB1, wave);
+    }
+    MI_WAIT_SYNC(MODE, flag, 0)
+    stamp();
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[0][i][0][j] = mfma_sel(i, af[i], b0f[j], acc[0][i][0][j], as_, b0s[j]);
+      for (int j = 0; j < 2; ++j) {
+        if (ZC) mfma_ba_zero<FA, FB>(af[i], b0f[j], acc[0][i][0][j], b0s[j]);
+        else acc[0][i][0][j] = mfma_sel(i, af[i], b0f[j], acc[0][i][0][j], as_, b0s[j]);
+      }
     MI_PIN(4, 2, acc[0][i][0][j])
     MI_PHASE_END();
+    stamp();
     // ---- phase 1: C[0][*][1][*]
+    if (MODE == 1) {
+      stage_n<nA1>(rsA, a1_voff, sa1, oth + kOffA1, wave);
+      if (flag && EPI4) epi_part(c0_t{}, c1_t{}, d_prev, bslot_prev, !ZC);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int j = 0; j < NB1; ++j) b1f[j] = read_frag(cur + kOffB1, wc * NB1 + j, lane);
-    stage_n<nA1>(rsA, a1_voff, sa1, oth + kOffA1, wave);
-    MI_WAIT_SYNC(after_epi, 1)
+    if (MODE != 1) stage_n<nA1>(rsA, a1_voff, sa1, oth + kOffA1, wave);
+    MI_WAIT_SYNC(MODE, flag, 1)
+    stamp();
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < NB1; ++j) acc[0][i][1][j] = mfma_sel(i, af[i], b1f[j], acc[0][i][1][j], as_, b1s[j]);
+      for (int j = 0; j < NB1; ++j) {
+        if (ZC) mfma_ba_zero<FA, FB>(af[i], b1f[j], acc[0][i][1][j], b1s[j]);
+        else acc[0][i][1][j] = mfma_sel(i, af[i], b1f[j], acc[0][i][1][j], as_, b1s[j]);
+      }
     MI_PIN(4, NB1, acc[0][i][1][j])
     MI_PHASE_END();
+    stamp();
     // ---- phase 2: C[1][*][1][*]
+    if (MODE == 1) {
+      stage_n<2>(rsA, a0_voff, sa2, cur + kOffA0, wave);
+      if (flag) {
+        if (EPI4) epi_part(c1_t{}, c0_t{}, d_prev, bslot_prev, !ZC);
+        else epi_part(c1_t{}, c2_t{}, d_prev, bslot_prev, !ZC);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int i = 0; i < MA1; ++i) af[i] = read_frag(cur + kOffA1, wr * MA1 + i, lane);
-    stage_n<2>(rsA, a0_voff, sa2, cur + kOffA0, wave);
-    MI_WAIT_SYNC(after_epi, 2)
+    if (MODE != 1) stage_n<2>(rsA, a0_voff, sa2, cur + kOffA0, wave);
+    MI_WAIT_SYNC(MODE, flag, 2)
+    stamp();
 #pragma unroll
     for (int i = 0; i < MA1; ++i)
 #pragma unroll
-      for (int j = 0; j < NB1; ++j) acc[1][i][1][j] = mfma_sel(i, af[i], b1f[j], acc[1][i][1][j], as1, b1s[j]);
+      for (int j = 0; j < NB1; ++j) {
+        if (ZC) mfma_ba_zero<FA, FB>(af[i], b1f[j], acc[1][i][1][j], b1s[j]);
+        else acc[1][i][1][j] = mfma_sel(i, af[i], b1f[j], acc[1][i][1][j], as1, b1s[j]);
+      }
     MI_PIN(MA1, NB1, acc[1][i][1][j])
     MI_PHASE_END();
+    stamp();
     // ---- phase 3: C[1][*][0][*]
     stage_n<2>(rsB, b0_voff, sb2, cur + kOffB0, wave);
-    MI_WAIT_SYNC(after_epi, 3)
+    if (MODE == 1) {
+      if (flag && EPI4) epi_part(c1_t{}, c1_t{}, d_prev, bslot_prev, !ZC);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    MI_WAIT_SYNC(MODE, flag, 3)
+    stamp();
 #pragma unroll
     for (int i = 0; i < MA1; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[1][i][0][j] = mfma_sel(i, af[i], b0f[j], acc[1][i][0][j], as1, b0s[j]);
+      for (int j = 0; j < 2; ++j) {
+        if (ZC) mfma_ba_zero<FA, FB>(af[i], b0f[j], acc[1][i][0][j], b0s[j]);
+        else acc[1][i][0][j] = mfma_sel(i, af[i], b0f[j], acc[1][i][0][j], as1, b0s[j]);
+      }
     MI_PIN(MA1, 2, acc[1][i][0][j])
     MI_PHASE_END();
+    stamp();
     // cursors follow the step
     ++s;
     advance(ti_1, kt_1, oa_1, ob_1, ra_1, rb_1, s + 1);
     advance(ti_2, kt_2, oa_2, ob_2, ra_2, rb_2, s + 2);
-  };
-
-  const int fr = lane & 15, fq = lane >> 4;
-  const int ecol = (fq & 1) * 16 + (fq >> 1) * 8;  // column of this lane's 8-wide piece after the permlane16 swap
-  const int d_voff = ((wr * (RA0 + RA1) + (PERM ? 4 : 1) * fr) * ldd + wc * (RB0 + RB1)) * 2;  // bytes, within the tile (half 0)
-  const int d_voff1 = (PERM && MA1 != 4) ? ((wr * (RA0 + RA1) + MA1 * fr) * ldd + wc * (RB0 + RB1)) * 2 : d_voff;  // half 1
-  auto epilogue = [&](int ti) {
-    int tm, tn;
-    tile_mn(ti, tm, tn);
-    const int d_tile = (tm * TBM * ldd + tn * TBN) * 2;  // uniform, bytes
-    float bv[2][2][4];
-    if (BIAS) {  // this wave's own LDS-DMA data: covered by the vmcnt waits of the last K-tile, no barrier needed
-      const uint8_t* bp = bbuf + ((ti & 1) * 8 + wave) * 256 + fq * 8;
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int j = 0; j < (b == 0 ? 2 : NB1); ++j) {
-          const uint2 w = *reinterpret_cast<const uint2*>(bp + (b * RB0 + j * 16) * 2);
-          bv[b][j][0] = __uint_as_float(w.x << 16);
-          bv[b][j][1] = __uint_as_float(w.x & 0xFFFF0000u);
-          bv[b][j][2] = __uint_as_float(w.y << 16);
-          bv[b][j][3] = __uint_as_float(w.y & 0xFFFF0000u);
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int i = 0; i < (a == 0 ? 4 : MA1); ++i)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const int soff = d_tile + ((a * RA0 + (PERM ? i : i * 16)) * ldd + b * RB0) * 2;
-          const int dvo = a == 0 ? d_voff : d_voff1;
-          if (b == 0 || NB1 == 2) {
-            v4f v0 = acc[a][i][b][0] * alpha, v1 = acc[a][i][b][1] * alpha;
-            if (BIAS) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                v0[e] += bv[b][0][e];
-                v1[e] += bv[b][1][e];
-              }
-            }
-            u32 p0x = pack_bf16x2(v0[0], v0[1]), p0y = pack_bf16x2(v0[2], v0[3]);
-            u32 p1x = pack_bf16x2(v1[0], v1[1]), p1y = pack_bf16x2(v1[2], v1[3]);
-            auto sx = __builtin_amdgcn_permlane16_swap(p0x, p1x, false, false);
-            auto sy = __builtin_amdgcn_permlane16_swap(p0y, p1y, false, false);
-            v4i o = {(int)sx[0], (int)sy[0], (int)sx[1], (int)sy[1]};
-            if (ABL == 1) {
-              asm volatile("" ::"v"(o));
-            } else {
-              // aux 16 = sc1: write-through, the line is not kept in this XCD's L2.  A tile's 128 KiB of output per CU
-              // (4 MiB per XCD = its whole L2) would otherwise evict the A/B panels the next tile streams:
-              // measured -5..6 % kernel time at K = 2048-4096 (tools/bench_kernels.py --which ksweep, algos 4 vs 17-19).
-              if (ABL == 4) __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)o, rsD, dvo + ecol * 2, soff, 0);  // plain (ablation)
-              else __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)o, rsD, dvo + ecol * 2, soff, 16);
-              // hipcc (ROCm 7.2) lets the next VALU overwrite the data registers of this 16-byte store (SGPR-offset
-              // form) with no wait state: lanes 12-15 of every 16-lane row then stored the NEXT block's unconverted
-              // fp32 (seen on MI355X, tools/debug_gemm.py).  Keep the registers live across the required wait states.
-              asm volatile("s_nop 1" ::"v"(o) : "memory");
-            }
-          } else {  // NB1 == 1: a single 16-column tile in the second column block -> 4 columns (8 B) per lane
-            v4f v0 = acc[a][i][1][0] * alpha;
-            if (BIAS) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v0[e] += bv[1][0][e];
-            }
-            typedef unsigned int v2u __attribute__((ext_vector_type(2)));
-            v2u o = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3])};
-            if (ABL == 1) {
-              asm volatile("" ::"v"(o));
-            } else {
-              __builtin_amdgcn_raw_buffer_store_b64(o, rsD, dvo + fq * 8, soff, 16);
-              asm volatile("s_nop 1" ::"v"(o) : "memory");
-            }
-          }
-          acc[a][i][b][0] = (v4f){0.f, 0.f, 0.f, 0.f};
-          acc[a][i][b][1] = (v4f){0.f, 0.f, 0.f, 0.f};
-        }
   };
 
   // SK: partial accumulators of slot `slot` (this wave's 32 KiB: [acc index][lane] x 16 B, whole 1-KiB lines per store)
@@ -895,30 +1072,69 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
           }
   };
 
-  int kt = SK ? sk_k0 : 0, ti = 0;
-  bool after = false;  // previous step ended with an epilogue whose stores are still in flight
-  for (int pair = 0; pair < total / 2; ++pair) {
-    ktile(buf0, buf1, after, 0);
-    ktile(buf1, buf0, false, 1);
-    after = false;
-    kt += 2;
-    if (kt == nk) {
-      if (SK && ti == 0 && sk_k0 != 0) {
-        partial_store(sk_v);
-      } else {
-        epilogue(ti);
-        after = true;
-      }
-      kt = 0;
-      ++ti;
-    }
+  unsigned long long dg_c0 = 0, dg_r0 = 0;
+  if (ABL == 8) {  // diagnostic build: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz around the whole tile walk
+    dg_c0 = __builtin_amdgcn_s_memtime();
+    dg_r0 = __builtin_amdgcn_s_memrealtime();
   }
-  if (wr == 0) __builtin_amdgcn_s_barrier();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (SK && kt != 0) {  // the range ended inside a tile: fetch the rest from the neighbour and finish it
-    partial_add(sk_v + 1);
-    epilogue(ti);
+  if constexpr (SK || !DEPI) {  // block epilogue after each tile (stream-K; DEPI = false is kept as the A/B baseline, algo 46)
+    int kt = SK ? sk_k0 : 0, ti = 0;
+    bool after = false;  // previous step ended with an epilogue whose stores are still in flight
+    for (int pair = 0; pair < total / 2; ++pair) {
+      ktile(c0_t{}, buf0, buf1, after, 0, 0, 0);
+      ktile(c0_t{}, buf1, buf0, false, 1, 0, 0);
+      after = false;
+      kt += 2;
+      if (kt == nk) {
+        if (SK && ti == 0 && sk_k0 != 0) {
+          partial_store(sk_v);
+        } else {
+          epilogue_block(ti, true);
+          after = true;
+        }
+        kt = 0;
+        ++ti;
+      }
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (SK && kt != 0) {  // the range ended inside a tile: fetch the rest from the neighbour and finish it
+      partial_add(sk_v + 1);
+      epilogue_block(ti, false);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  } else {
+    int d_prev = 0;
+    for (int ti = 0; ti < my_tiles; ++ti) {
+      const bool have_prev = ti > 0;
+      ktile(c1_t{}, buf0, buf1, have_prev, 0, d_prev, (ti - 1) & 1);
+      ktile(c2_t{}, buf1, buf0, have_prev, 1, 0, 0);
+      for (int pair = 1; pair < nk / 2; ++pair) {
+        ktile(c0_t{}, buf0, buf1, false, 0, 0, 0);
+        ktile(c0_t{}, buf1, buf0, false, 1, 0, 0);
+      }
+      d_prev = tile_d_off(ti);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (my_tiles > 0) epilogue_block(my_tiles - 1, false);
+    if (ABL == 9) {
+      if (blockIdx.x == 0 && (wave & 3) == 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        unsigned long long* dbg = (unsigned long long*)bias + (wave >> 2) * 1024;
+        for (int i = lane; i < 1024; i += 64) dbg[i] = i < stamp_idx ? stamp_lds[i] : 0ull;
+      }
+    }
+    if (ABL == 8) {  // `bias` is a u64[4 * gridDim.x] buffer of its own: {cycles, 100 MHz ticks, steps, xcc id}
+      const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+      if (tid == 0) {
+        unsigned long long* dbg = (unsigned long long*)bias + (size_t)bid * 4;
+        dbg[0] = c1 - dg_c0;
+        dbg[1] = r1 - dg_r0;
+        dbg[2] = (unsigned long long)total;
+        dbg[3] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID[3:0]
+      }
+    }
   }
 #undef MI_WAIT_SYNC
 #undef MI_PIN
@@ -991,7 +1207,7 @@ static int sk_units(int64_t M, int64_t N, int64_t K, bool force) {
   return U >= nk ? (int)U : 0;
 }
 
-template <int FA, int FB, bool MX, bool BIAS, int ABL, int MA1, int NB1>
+template <int FA, int FB, bool MX, bool BIAS, int ABL, int MA1, int NB1, bool DEPI = true>
 static void launch_p8_cfg(const uint8_t* a, const uint8_t* b, uint16_t* D, const float* sa_inv, const float* sb_inv,
                           const uint8_t* SA, const uint8_t* SB, const uint16_t* bias, int64_t M, int64_t N, int64_t K,
                           int64_t lda, int64_t ldb, int64_t ldd, hipStream_t st, bool one_tile_per_wg = false) {
@@ -1000,9 +1216,10 @@ static void launch_p8_cfg(const uint8_t* a, const uint8_t* b, uint16_t* D, const
   // one_tile_per_wg (algo 5): same kernel, one workgroup per tile, so the hardware dispatcher balances the tiles over whatever
   // CUs are free -- the form to use while other kernels (RCCL collectives) hold part of the chip
   const int grid = (one_tile_per_wg || tiles_m * tiles_n < num_cus()) ? tiles_m * tiles_n : num_cus();
-  hipLaunchKernelGGL((gemm_256_p8<FA, FB, ABL, MX, BIAS, MA1, NB1, false>), dim3(grid), dim3(512), 0, st, a, b, D, sa_inv, sb_inv, (int)K,
+  const int stagger = ((ABL == 3) && getenv("MI_GEMM_STAGGER")) ? atoi(getenv("MI_GEMM_STAGGER")) : 0;  // experiment knob (algo 16)
+  hipLaunchKernelGGL((gemm_256_p8<FA, FB, ABL, MX, BIAS, MA1, NB1, false, DEPI>), dim3(grid), dim3(512), 0, st, a, b, D, sa_inv, sb_inv, (int)K,
                      (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb), (int)(M * ldd * 2), SA, SB,
-                     (int)M, (int)N, bias, (float*)nullptr, (unsigned int*)nullptr, 0u, 0);
+                     (int)M, (int)N, bias, (float*)nullptr, (unsigned int*)nullptr, 0u, stagger);
 }
 
 template <int FA, int FB, bool MX, bool BIAS>
@@ -1061,16 +1278,41 @@ static int launch_p8(const uint8_t* a, const uint8_t* b, uint16_t* D, const floa
     case 2: MI_P8(MXv, BIASv, ABLv, 2, 2); break;                   \
     default: MI_P8(MXv, BIASv, ABLv, 2, 1); break;                  \
   }
-  if (algo == 15) {
-    MI_P8_CFG(false, false, 1)
-  } else if (algo == 16) {
-    MI_P8_CFG(false, false, 3)
-  } else if (algo == 17) {
-    MI_P8_CFG(false, false, 4)
-  } else if (algo == 18) {  // timing ablation: block scales staged into LDS but not read (unit scales): wrong results
-    MI_P8_CFG(true, false, 5)
-  } else if (algo == 19) {  // timing ablation: block scales staged and read, MFMAs still get unit scales: wrong results
-    MI_P8_CFG(true, false, 6)
+  if (algo == 46 || (algo >= 15 && algo <= 24)) {  // timing-only / diagnostic builds: E4M3 x E4M3 only (compile time)
+    if constexpr (FA == 0 && FB == 0) {
+      if (algo == 46) {  // A/B baseline: block epilogue after each tile (the round-1 form)
+        switch (cfg) {
+          case 0: launch_p8_cfg<FA, FB, false, false, 0, 4, 2, false>(a, b, D, sa_inv, sb_inv, SA, SB, bias, M, N, K, lda, ldb, ldd, st); break;
+          case 1: launch_p8_cfg<FA, FB, false, false, 0, 4, 1, false>(a, b, D, sa_inv, sb_inv, SA, SB, bias, M, N, K, lda, ldb, ldd, st); break;
+          case 2: launch_p8_cfg<FA, FB, false, false, 0, 2, 2, false>(a, b, D, sa_inv, sb_inv, SA, SB, bias, M, N, K, lda, ldb, ldd, st); break;
+          default: launch_p8_cfg<FA, FB, false, false, 0, 2, 1, false>(a, b, D, sa_inv, sb_inv, SA, SB, bias, M, N, K, lda, ldb, ldd, st); break;
+        }
+      } else if (algo == 15) {  // no stores
+        MI_P8_CFG(false, false, 1)
+      } else if (algo == 16) {  // start stagger (MI_GEMM_STAGGER)
+        MI_P8_CFG(false, false, 3)
+      } else if (algo == 17) {  // plain (write-back) stores
+        MI_P8_CFG(false, false, 4)
+      } else if (algo == 20) {  // every tile reads the operand panels of tile (0, 0) (L2-resident): wrong results
+        MI_P8_CFG(false, false, 7)
+      } else if (algo == 22) {  // `bias` is a u64[2048] buffer: per-phase s_memtime stamps of waves 0 and 4 of workgroup 0
+        MI_P8_CFG(false, false, 9)
+      } else if (algo == 21) {  // `bias` is a u64[4 * grid] stamp buffer (cycles, 100 MHz ticks, steps, XCC id)
+        MI_P8_CFG(false, false, 8)
+      } else if (algo == 24) {  // A/B baseline: half-line epilogue stores (16 rows x 64 B per instruction)
+        MI_P8_CFG(false, false, 11)
+      } else if (algo == 18) {  // block scales staged into LDS but not read (unit scales): wrong results
+        MI_P8_CFG(true, false, 5)
+      } else if (algo == 19) {  // block scales staged and read, MFMAs still get unit scales: wrong results
+        MI_P8_CFG(true, false, 6)
+      } else {
+        set_error("mi_gemm: unknown diagnostic algo %d", algo);
+        return MI_ERR_ARG;
+      }
+    } else {
+      set_error("mi_gemm: diagnostic algo %d is built for E4M3 x E4M3 only", algo);
+      return MI_ERR_ARG;
+    }
   } else if (mx) {
     if (bias) { MI_P8_CFG(true, true, 0) } else { MI_P8_CFG(true, false, 0) }
   } else {
@@ -1096,7 +1338,7 @@ static int launch_fmt(const void* A, const void* B, void* D, const float* sa_inv
     int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
     hipLaunchKernelGGL((gemm_256_8ph<FA, FB, OUT>), dim3(tiles_m * tiles_n), dim3(512), 0, st, a, b, D, sa_inv, sb_inv,
                        bp, (int)M, (int)N, (int)K, lda, ldb, ldd, tiles_m, tiles_n);
-  } else if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 19) || (algo >= 40 && algo <= 45)) {
+  } else if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 24) || (algo >= 40 && algo <= 46)) {
     return launch_p8<FA, FB>(a, b, (uint16_t*)D, sa_inv, sb_inv, (const uint8_t*)SA, (const uint8_t*)SB, bp, M, N, K, lda, ldb, ldd,
                              algo, mx, st);
   } else if (algo == 13 && !mx) {
@@ -1156,7 +1398,7 @@ static int pick_algo(int algo, int64_t M, int64_t N, int64_t K, int64_t lda, int
   const bool p8_ok = (M % 256 == 0 || M % 192 == 0) && (N % 256 == 0 || N % 192 == 0) && M > 0 && N > 0 && K > 0 &&
                      (K % (2 * BK) == 0) && out == 0 && M * lda < (1LL << 31) && N * ldb < (1LL << 31) &&
                      M * ldd * 2 < (1LL << 31);
-  if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 19) || (algo >= 40 && algo <= 45)) {
+  if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 24) || (algo >= 40 && algo <= 46)) {
     if (!p8_ok) {
       set_error("%s: algo %d needs M,N %% 256 (or 192) == 0, K %% 256 == 0, bf16 output, operands < 2 GiB", who, algo);
       return MI_ERR_SHAPE;

@@ -2,6 +2,7 @@
 import argparse
 import os
 import sys
+import time
 
 import torch
 
@@ -122,6 +123,56 @@ def main():
                 out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
                 t = time_fn(lambda: ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=algo), args.iters)
                 print(f"ksweep algo {algo} K={k:5d}: {t*1e6:9.1f} us  per-round {t*1e6/4:8.1f} us  {2.0*m*n*k/t/1e12:8.1f} TFLOP/s", flush=True)
+    if "stagger" in args.which:  # start stagger of the persistent kernel (algo 16 + MI_GEMM_STAGGER units of 512 cycles per class)
+        shapes = [(8192, 8192, 2048), (8192, 8192, 4096), (8192, 16384, 3072), (8192, 3072, 16384), (16384, 3072, 8192), (8192, 3072, 8192), (8192, 8192, 3072), (8192, 5120, 3072), (8192, 3072, 3072)]
+        for (m, n, k) in shapes:
+            a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
+            out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+            def mk(units):
+                def f():
+                    os.environ["MI_GEMM_STAGGER"] = str(units)
+                    ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=16)
+                return f
+            fns = {"block46": (lambda: ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=46)),
+                   "algo4": (lambda: ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=4))}
+            fns["half24"] = (lambda: ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=24))
+            res = time_interleaved(fns, rounds=8, inner=6)
+            print(f"stagger {m}x{n}x{k}: " + "  ".join(f"{al}: {t*1e6:7.1f} us {2.0*m*n*k/t/1e12:6.0f} TF" for al, t in res.items()), flush=True)
+    if "stamps" in args.which:  # per-phase timeline of workgroup 0 (algo 22), around the tile boundaries
+        from llm_fp8_amd import _lib
+        lib = _lib.load()
+        st = torch.cuda.current_stream().cuda_stream
+        for (m, n, k) in ((8192, 8192, 2048), (8192, 16384, 3072), (8192, 8192, 3072)):
+            a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
+            out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+            dbg = torch.zeros((2, 1024), dtype=torch.int64, device=dev)
+            def run(algo, bias_ptr):
+                rc = lib.mi_gemm_fp8(a.data_ptr(), b.data_ptr(), out.data_ptr(), one.data_ptr(), one.data_ptr(), bias_ptr,
+                                     m, n, k, k, k, n, 0, 0, 0, algo, st)
+                assert rc == 0, lib.mi_last_error()
+            for _ in range(300):
+                run(4, None)
+            run(22, dbg.data_ptr())
+            torch.cuda.synchronize()
+            d = dbg.cpu().numpy()
+            nk = k // 128
+            for grp in (0, 1):
+                t = d[grp]
+                t = t[t > 0]
+                # stamps alternate: A (start of MFMA segment), B (end of phase); 8 per K-tile
+                A, B = t[0::2], t[1::2]
+                nph = min(len(A), len(B))
+                load_seg = A[1:nph] - B[:nph - 1]      # end of phase p-1 -> MFMA start of phase p (fragment reads, issues, wait, barrier)
+                mfma_seg = B[:nph] - A[:nph]
+                per_kt = (B[4:nph:4] - B[0:nph - 4:4])
+                print(f"stamps {m}x{n}x{k} group {grp}: {nph} phases; cycles per K-tile: " + " ".join(str(int(x)) for x in per_kt[:3 * nk]), flush=True)
+                for ti in range(1, 3):
+                    base = ti * nk * 4
+                    if base + 12 > nph:
+                        break
+                    lo = base - 12
+                    print(f"   boundary into tile {ti}, K-tiles nk-3 .. +2, per phase [load/wait seg | mfma seg]: "
+                          + "  ".join((("|| " if (x - base) % 4 == 0 else "") + f"{int(load_seg[x - 1])}/{int(mfma_seg[x])}") for x in range(lo, base + 12)), flush=True)
     if "clock" in args.which:
         from llm_fp8_amd import _lib
         lib = _lib.load()
@@ -149,6 +200,38 @@ def main():
                 print(f"clock {fill:6s} K={k}: loop cycles/K-tile median {float((cyc / (k/128)).median()):8.1f} "
                       f"in-kernel clock median {float(clk.median()):7.1f} MHz (min {float(clk.min()):.0f} max {float(clk.max()):.0f}); "
                       f"no-store kernel {t*1e6:8.1f} us = {2.0*m*n*k/t/1e12:7.1f} TFLOP/s", flush=True)
+    if "pclock" in args.which:  # in-kernel clock of the PERSISTENT kernel (algo 21 = stamped build), per decoder GEMM site, random data
+        from llm_fp8_amd import _lib
+        lib = _lib.load()
+        st = torch.cuda.current_stream().cuda_stream
+        shapes = [(8192, 8192, 8192)] + [s for name, (M, N, K) in SHAPES_3B.items() for s in ((M, N, K), (M, K, N), (N, K, M))]
+        for (m, n, k) in shapes:
+            for fill in ("random", "zeros"):
+                a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
+                if fill == "zeros":
+                    a.zero_(); b.zero_()
+                out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+                dbg = torch.zeros((256, 4), dtype=torch.int64, device=dev)
+                def run(algo, bias_ptr):
+                    rc = lib.mi_gemm_fp8(a.data_ptr(), b.data_ptr(), out.data_ptr(), one.data_ptr(), one.data_ptr(), bias_ptr,
+                                         m, n, k, k, k, n, 0, 0, 0, algo, st)
+                    assert rc == 0, lib.mi_last_error()
+                t0 = time.time()
+                while time.time() - t0 < (2.0 if fill == "random" else 1.0):  # heat up: >= 2 s back to back
+                    for _ in range(50):
+                        run(4, None)
+                    torch.cuda.synchronize()
+                run(21, dbg.data_ptr())
+                torch.cuda.synchronize()
+                d = dbg.cpu().double()
+                d = d[d[:, 1] > 0]
+                clk = d[:, 0] / d[:, 1] * 100.0
+                cyc_per_step = d[:, 0] / d[:, 2]
+                t = time_fn(lambda: run(4, None), args.iters)
+                tf = 2.0 * m * n * k / t / 1e12
+                print(f"pclock {m}x{n}x{k} {fill:6s}: clock median {float(clk.median()):7.1f} MHz (min {float(clk.min()):.0f} max {float(clk.max()):.0f}) "
+                      f"cycles/K-tile-step median {float(cyc_per_step.median()):7.1f} (ideal 2048)  {t*1e6:8.1f} us {tf:7.1f} TF "
+                      f"= {tf/5000*100:4.1f}% of 5 PF = {tf/(5000*float(clk.median())/2400)*100:4.1f}% at clock", flush=True)
     if "cast" in args.which:
         for (R, C) in ((8192, 3072), (8192, 16384), (16384, 3072), (8192, 8192)):
             x = torch.randn((R, C), device=dev, dtype=torch.float32, generator=g).to(torch.bfloat16)
