@@ -17,7 +17,9 @@
  *     (PyTorch caching allocator); the library allocates nothing persistent.
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no
  *     internal synchronisation, no global mutable state besides the thread-local
- *     error string.
+ *     error string -- with ONE documented exception: mi_gemm_set_workspace binds a
+ *     caller-owned stream-K workspace to the current device (per-device table, used
+ *     only by the explicit algo 44; never touched by the automatic choice).
  *   - return 0 on success, <0 on error: -1 invalid argument, -2 unsupported shape,
  *     -3 HIP runtime error.  mi_last_error() gives the message (thread-local).
  *   - matrices are row-major; `fmt`: 0 = OCP E4M3FN, 1 = OCP E5M2.
@@ -47,7 +49,14 @@ extern "C" {
 #define MI_AMAX_ALGO_MAX 0
 #define MI_AMAX_ALGO_MOST_RECENT 1
 
-/* ABI version, bumped on any signature change. */
+/* ABI version: bumped whenever an entry point is added, removed or changes its signature or the meaning of an argument.
+ * mi_abi_version() returns the value the library was built with; a binding compares it with the header it was written
+ * against (llm_fp8_amd/_lib.py does at load time).
+ *   1  round 1 (the surface of SURVEY.md 8b + fused neighbours)
+ *   2  round 2: mi_gemm_fp8 / mi_gemm_mxfp8 algo values 20-24, 46 (diagnostic builds), mi_adamw_cast_bf16_multi,
+ *      mi_gemm_fp8_grouped
+ */
+#define MI_ABI_VERSION 2
 int mi_abi_version(void);
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* mi_last_error(void);

@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "libmi_fp8.so")
 
 MI_FMT_E4M3 = 0
 MI_FMT_E5M2 = 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_i64 = ctypes.c_int64
 _c_int = ctypes.c_int

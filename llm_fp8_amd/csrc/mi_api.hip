@@ -20,7 +20,7 @@ int hip_fail(hipError_t e, const char* what) {
 
 }  // namespace mi
 
-extern "C" int mi_abi_version(void) { return 1; }
+extern "C" int mi_abi_version(void) { return MI_ABI_VERSION; }
 
 extern "C" const char* mi_last_error(void) { return mi::g_err; }
 

@@ -562,6 +562,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   }
   const int my_tiles = SK ? 0 : (ntiles - bid + G - 1) / G;  // tiles bid, bid + G, ...
   const float alpha = MX ? 1.0f : (*sa_inv) * (*sb_inv);
+  const int total_tiles_hint = SK ? (sk_total + sk_k0 + nk - 1) / nk : my_tiles;  // tiles this workgroup touches
   const rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
   const rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
   const rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)D, 0, d_bytes, 0x00020000);
@@ -633,11 +634,30 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
     if (SK) tile_of_flat(sk_t0 + ti, tiles_m, tiles_n, tm, tn);
     else tile_of_block(bid + ti * G, ntiles, tiles_m, tiles_n, tm, tn);
   };
-  auto tile_origin = [&](int ti, int& oa, int& ob, int& ra, int& rb) {
+  // Lane i keeps the origin (first row of A, first row of B) of this workgroup's i-th tile: ONE vector evaluation of the tile map
+  // at kernel start.  The map costs three integer divisions; evaluated at every tile switch (twice per tile, once per prefetch
+  // cursor, plus once for the output offset) it held both wave groups for ~300 cycles each time with the matrix pipes idle
+  // (per-phase stamps, tools/bench_kernels.py --which stamps).  Tiles beyond the 64th fall back to the scalar evaluation.
+  int tab_ra, tab_rb;
+  {
     int tm, tn;
-    tile_mn(ti, tm, tn);
-    ra = tm * TBM;
-    rb = tn * TBN;
+    tile_mn(min(lane, max(total_tiles_hint - 1, 0)), tm, tn);
+    tab_ra = tm * TBM;
+    tab_rb = tn * TBN;
+  }
+  auto tile_rc = [&](int ti, int& ra, int& rb) {
+    if (ti < 64) {
+      ra = __builtin_amdgcn_readlane(tab_ra, ti);
+      rb = __builtin_amdgcn_readlane(tab_rb, ti);
+    } else {
+      int tm, tn;
+      tile_mn(ti, tm, tn);
+      ra = tm * TBM;
+      rb = tn * TBN;
+    }
+  };
+  auto tile_origin = [&](int ti, int& oa, int& ob, int& ra, int& rb) {
+    tile_rc(ti, ra, rb);
     if (ABL == 7) ra = rb = 0;  // timing ablation: every tile streams the panels of tile (0, 0) -> all operand reads hit L2
     oa = ra * lda;
     ob = rb * ldb;
@@ -749,9 +769,9 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   const int d_voff = ((wr * (RA0 + RA1) + (PERM ? 4 : 1) * fr) * ldd + wc * (RB0 + RB1)) * 2;  // bytes, within the tile (half 0)
   const int d_voff1 = (PERM && MA1 != 4) ? ((wr * (RA0 + RA1) + MA1 * fr) * ldd + wc * (RB0 + RB1)) * 2 : d_voff;  // half 1
   auto tile_d_off = [&](int ti) -> int {  // uniform byte offset of tile ti's output
-    int tm, tn;
-    tile_mn(ti, tm, tn);
-    return (tm * TBM * ldd + tn * TBN) * 2;
+    int ra, rb;
+    tile_rc(ti, ra, rb);
+    return (ra * ldd + rb) * 2;
   };
   // whole-line form (NB1 == 2): lane (m = fr, q = fq) of the first store of a fragment pair covers row m & 7, the second row
   // 8 + (m & 7); lanes m >= 8 carry the second 32-column block of those rows

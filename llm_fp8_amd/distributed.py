@@ -180,10 +180,20 @@ class GradArenaDP(torch.nn.Module):
                 ids = torch.cat(ids_l) if len(ids_l) > 1 else ids_l[0]
                 dy = (torch.cat(dy_l) if len(dy_l) > 1 else dy_l[0]).to(p.dtype).contiguous()
                 if self.world > 1:
-                    ids_all = torch.empty(self.world * ids.numel(), dtype=ids.dtype, device=ids.device)
-                    dy_all = torch.empty((self.world * dy.shape[0], dy.shape[1]), dtype=dy.dtype, device=dy.device)
+                    # Ranks may hold different token counts: the reference's collator pads every batch to ITS OWN longest
+                    # sequence (data.py:59-63), and micro-batches accumulate under no_sync.  Exchange the counts first (one
+                    # tiny all_gather), pad ids with -1 (skipped by the scatter) and dy with zero rows up to the largest.
+                    cnt = torch.tensor([ids.numel()], dtype=torch.int64, device=ids.device)
+                    cnts = torch.empty(self.world, dtype=torch.int64, device=ids.device)
+                    dist.all_gather_into_tensor(cnts, cnt, group=self.group)
+                    tmax = int(cnts.max().item())
+                    if ids.numel() < tmax:
+                        ids = torch.cat([ids, ids.new_full((tmax - ids.numel(),), -1)])
+                        dy = torch.cat([dy, dy.new_zeros((tmax - dy.shape[0], dy.shape[1]))])
+                    ids_all = torch.empty(self.world * tmax, dtype=ids.dtype, device=ids.device)
+                    dy_all = torch.empty((self.world * tmax, dy.shape[1]), dtype=dy.dtype, device=dy.device)
                     dist.all_gather_into_tensor(ids_all, ids.contiguous(), group=self.group)
-                    dist.all_gather_into_tensor(dy_all, dy, group=self.group)
+                    dist.all_gather_into_tensor(dy_all, dy.contiguous(), group=self.group)
                 else:
                     ids_all, dy_all = ids, dy
                 buf = p._mi_grad_buf
@@ -287,7 +297,9 @@ def add_embedding_rows_(grad: torch.Tensor, dy: torch.Tensor, ids: torch.Tensor,
         from .pytorch import ops
         ops.embedding_grad_add_(grad, dy, ids, alpha, pad)
         return
-    dense = torch.ops.aten.embedding_dense_backward(dy.reshape(-1, dy.shape[-1]).to(grad.dtype).contiguous(), ids.reshape(-1),
+    ids = ids.reshape(-1)
+    ids = torch.where(ids < 0, torch.zeros_like(ids), ids)  # padding entries (-1) carry zero rows: route them to row 0
+    dense = torch.ops.aten.embedding_dense_backward(dy.reshape(-1, dy.shape[-1]).to(grad.dtype).contiguous(), ids,
                                                     grad.shape[0], pad, False)
     grad.add_(dense, alpha=alpha)
 

@@ -174,6 +174,22 @@ class TELlamaForCausalLM:
         return model
 
     @classmethod
+    def from_pretrained_local(cls, pretrained_model_name_or_path, *args, config, scenario: str = "default",
+                              torch_dtype=torch.bfloat16, **kwargs):
+        """te_llama.py:100-178: build the TE-layer model, then copy a LOCAL safetensors checkpoint (single file or
+        `model.safetensors.index.json` shards) into it shard by shard: `replace_params` for the fused TE names,
+        `load_state_dict(strict=False)` for the rest.  Weights-only loading (safetensors); nothing is downloaded."""
+        from . import checkpoint
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(torch_dtype)
+        try:
+            model = cls(config, scenario)
+        finally:
+            torch.set_default_dtype(prev)  # the reference never restores it (SURVEY.md Appendix C.5)
+        checkpoint.load_into(model, str(pretrained_model_name_or_path), config)
+        return model
+
+    @classmethod
     def from_hf_state_dict(cls, hf_state_dict, config, scenario: str = "default", torch_dtype=torch.bfloat16):
         """Offline counterpart of from_pretrained_local (te_llama.py:100-178): same copy rules, the state dict is
         handed in instead of being read from a hub snapshot."""

@@ -3,6 +3,7 @@ tokens with label != -100) computed by two streaming HIP kernels directly on the
 from __future__ import annotations
 
 import os
+import weakref
 
 import torch
 
@@ -33,6 +34,10 @@ class _CEFn(torch.autograd.Function):
         gscale = (dloss.to(torch.float32) / n_valid).reshape(1).contiguous()
         st = torch.cuda.current_stream().cuda_stream
         h = ctx.handoff
+        if h is not None and h.offered():
+            from .pytorch.module import handoff_readers
+            if handoff_readers(None if h.act_ref is None else h.act_ref()):
+                h = None  # somebody reads d(logits): produce it for real
         if h is not None and h.offered() and not h.mx and T % 8 == 0:
             y = torch.empty((T, V), dtype=torch.uint8, device=logits2d.device) if h.want_y else None
             yt = torch.empty((V, T), dtype=torch.uint8, device=logits2d.device) if h.want_t else None
@@ -65,4 +70,6 @@ def causal_lm_loss(logits: torch.Tensor, labels: torch.Tensor, vocab_size: int =
     handoff = getattr(logits, "_mi_dy_handoff", None)
     if not l2.is_contiguous() or os.environ.get("LLM_FP8_AMD_NO_DY_HANDOFF") == "1":
         l2, handoff = l2.contiguous(), None  # (a copy sits between the lm_head and the loss: no hand-off)
+    if handoff is not None:
+        handoff.act_ref = weakref.ref(logits)  # hooks / retain_grad() put on the logits before backward turn the hand-off off
     return _CEFn.apply(l2, shift_labels.reshape(-1).to(torch.int64).contiguous(), handoff)

@@ -36,7 +36,9 @@ class ClippedAdamW(torch.optim.Optimizer):
         """Device tables of one parameter group for the multi-tensor kernels.  The chunk list only depends on the tensor sizes
         and is built once; the address table is re-uploaded when an address changed (gradients are new tensors every step,
         though the caching allocator usually hands back the same blocks)."""
-        key = id(group_items[0][0])
+        # one plan per PARTITION (the parameters of a group that share a step count), not per group: two partitions of one
+        # group must not share address table / partial sums
+        key = (id(group_items[0][0]), tuple(id(p) for _, p in group_items))
         sizes = tuple(p.numel() for _, p in group_items)
         plan = self._plans.get(key)
         if plan is None or plan["sizes"] != sizes:
@@ -47,6 +49,7 @@ class ClippedAdamW(torch.optim.Optimizer):
             plan = {"sizes": sizes, "chunks": chunks, "n_chunks": len(refs), "addr": None,
                     "table": torch.empty((5, len(sizes)), dtype=torch.int64, device=dev),
                     "host": [torch.empty((5, len(sizes)), dtype=torch.int64).pin_memory() for _ in range(2)], "flip": 0,
+                    "uploaded": [None, None],
                     "partials": torch.empty(len(refs), dtype=torch.float32, device=dev)}
             self._plans[key] = plan
         rows = [[], [], [], [], list(sizes)]
@@ -57,10 +60,19 @@ class ClippedAdamW(torch.optim.Optimizer):
             rows[2].append(st["exp_avg"].data_ptr())
             rows[3].append(st["exp_avg_sq"].data_ptr())
         if plan["addr"] != rows:
-            host = plan["host"][plan["flip"]]  # two pinned staging buffers: the previous async copy may still be in flight
+            # two pinned staging buffers, each guarded by an event recorded behind its last upload: the host may run several
+            # steps ahead of the device, and rewriting a buffer whose async H2D copy has not run yet would hand the kernels
+            # the addresses of a LATER step
+            slot = plan["flip"]
             plan["flip"] ^= 1
+            if plan["uploaded"][slot] is not None:
+                plan["uploaded"][slot].synchronize()
+            host = plan["host"][slot]
             host.copy_(torch.tensor(rows, dtype=torch.int64))
             plan["table"].copy_(host, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            plan["uploaded"][slot] = ev
             plan["addr"] = rows
         return plan
 
@@ -80,6 +92,8 @@ class ClippedAdamW(torch.optim.Optimizer):
                 state["step"] = 0
                 state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if torch.is_tensor(state["step"]):  # a state_dict written by torch's AdamW keeps `step` as a tensor
+                state["step"] = int(state["step"].item())
             if not p.grad.is_contiguous():
                 p.grad = p.grad.contiguous()
             assert p.is_contiguous()

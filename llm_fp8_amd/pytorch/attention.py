@@ -9,13 +9,14 @@ torch `scaled_dot_product_attention` otherwise."""
 from __future__ import annotations
 
 import os
+import weakref
 from typing import Optional
 
 import torch
 import torch.nn.functional as F
 
 from . import ops
-from .module import DyHandoff, LayerNormLinear, Linear
+from .module import DyHandoff, LayerNormLinear, Linear, handoff_readers
 
 __all__ = ["RotaryPositionEmbedding", "apply_rotary_pos_emb", "DotProductAttention", "MultiheadAttention"]
 
@@ -92,6 +93,7 @@ class _RoPESplitFn(torch.autograd.Function):
         ctx.save_for_backward(cos, sin)
         ctx.meta = (B, S, n_q, n_kv, d)
         ctx.handoff = handoff
+        ctx.act_ref = weakref.ref(qkv) if handoff is not None else None  # to see hooks / retain_grad put on it before backward
         return q.view(B, S, n_q, d), k.view(B, S, n_kv, d), v.view(B, S, n_kv, d)
 
     @staticmethod
@@ -100,6 +102,8 @@ class _RoPESplitFn(torch.autograd.Function):
         B, S, n_q, n_kv, d = ctx.meta
         T = B * S
         h = ctx.handoff
+        if h is not None and h.offered() and handoff_readers(ctx.act_ref()):
+            h = None  # somebody reads d(qkv): produce it for real
         if h is not None and h.offered() and d == 128 and T % (32 if h.mx else 8) == 0:
             args = (dq.reshape(T, n_q * d), dk.reshape(T, n_kv * d), dv.reshape(T, n_kv * d), cos, sin, n_q, n_kv, d, S)
             if h.mx:

@@ -41,11 +41,14 @@ class DyHandoff:
     known in advance); the producer's backward (attention._RoPESplitFn) then emits the FP8 copies itself, `put`s them here and
     returns an UNWRITTEN bf16 placeholder as the autograd gradient; the Linear's backward `take`s the copies and never reads
     the placeholder.  One object per forward call, private to the module that wires the two together: nothing else may sit
-    between them in the graph.  `take` checks that the gradient it was handed is that placeholder and fails loudly otherwise."""
-    __slots__ = ("scale", "amax", "fmt", "want_y", "want_t", "fp8", "ptr", "mx")
+    between them in the graph.  `take` checks that the gradient it was handed is that placeholder and fails loudly otherwise.
+    Guard: a producer asks `handoff_readers` first -- with a tensor hook or `retain_grad()` on the activation in between, or
+    under anomaly mode, it writes the real gradient and the hand-off is skipped for that backward pass."""
+    __slots__ = ("scale", "amax", "fmt", "want_y", "want_t", "fp8", "ptr", "mx", "act_ref")
 
     def __init__(self):
         self.scale = self.amax = self.fmt = self.fp8 = self.ptr = None
+        self.act_ref = None  # weakref to the activation the user can reach (the logits): see handoff_readers
         self.want_y = self.want_t = self.mx = False
 
     def offer(self, scale, amax, fmt, want_y, want_t, mx: bool = False):
@@ -68,6 +71,18 @@ class DyHandoff:
                                "(an op was inserted between the q|k|v projection and the rotary split)")
         fp8, self.fp8, self.ptr = self.fp8, None, None
         return fp8
+
+
+def handoff_readers(t) -> bool:
+    """True when something may READ the bf16 gradient that flows from a DyHandoff producer to its Linear: a tensor hook or
+    `retain_grad()` on the activation between them (`t`, the producer's input), or autograd's anomaly mode (it scans every
+    gradient for NaNs).  The producer then takes its ordinary route -- it writes the real gradient, `put`s nothing, and the
+    Linear quantises what it receives -- instead of handing an unwritten placeholder to code that would read garbage."""
+    if torch.is_anomaly_enabled():
+        return True
+    if t is None:
+        return False
+    return bool(getattr(t, "retains_grad", False)) or bool(getattr(t, "_backward_hooks", None))
 
 
 class _GemmSpec:
@@ -493,6 +508,9 @@ class _FP8Module(torch.nn.Module):
         self._meta_key = None
         self._pending_state = None
         self._wcache = {}  # FP8 weights kept across micro-batches (is_first_microbatch protocol)
+        # used when forward() is called without `is_first_microbatch` (the decoder layer does not thread the flag through):
+        # the training harness sets it per micro-batch of a gradient-accumulation window (train.train_step)
+        self.default_is_first_microbatch = None
 
     def _prepare(self, device) -> Optional[Tuple[Recipe, Optional[ModuleMeta], Optional[ModuleMeta], bool]]:
         """Called at the top of forward.  None -> run the plain bf16 path."""
@@ -593,6 +611,8 @@ class Linear(_FP8Module):
         self.use_bias = bias
 
     def forward(self, inp: torch.Tensor, is_first_microbatch=None) -> torch.Tensor:
+        if is_first_microbatch is None:
+            is_first_microbatch = self.default_is_first_microbatch
         st = self._prepare(inp.device)
         if st is None:
             return F.linear(inp, self.weight.to(inp.dtype), None if self.bias is None else self.bias.to(inp.dtype))
@@ -671,6 +691,8 @@ class LayerNormLinear(_FP8Module):
         """`_with_skip` (extension used by MultiheadAttention / the decoder layer): returns (out, skip) where `skip` carries
         `inp` for the residual add, its gradient fused into the RMSNorm backward when the fused-norm path is active.
         `_rstd`: (rstd, eps) of `inp` from residual_add_stats, used instead of a statistics pass when eps matches."""
+        if is_first_microbatch is None:
+            is_first_microbatch = self.default_is_first_microbatch
         st = self._prepare(inp.device)
         ws, b = self._weights(), self._bias()
         if st is not None and _can_fuse_norm(self, st[0], inp) and not self.return_layernorm_output:
@@ -754,6 +776,8 @@ class LayerNormMLP(_FP8Module):
         return _layernorm(x, self.layer_norm_weight, self.layer_norm_bias, self.eps, self.zero_centered_gamma)
 
     def forward(self, inp: torch.Tensor, is_first_microbatch=None, _with_skip: bool = False, _rstd=None):
+        if is_first_microbatch is None:
+            is_first_microbatch = self.default_is_first_microbatch
         st = self._prepare(inp.device)
         if (st is not None and self.activation == "swiglu" and self.fused_swiglu and _can_fuse_norm(self, st[0], inp)):
             recipe, mf, mb, first = st  # K9 + K10: norm -> cast, fc1, SwiGLU -> cast, fc2 in one autograd node

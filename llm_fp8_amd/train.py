@@ -10,6 +10,7 @@ FULL_SHARD around each decoder layer (`:381-460`) or DDP (`:355-378`).
 from __future__ import annotations
 
 import argparse
+import contextlib
 import functools
 import json
 import math
@@ -42,6 +43,8 @@ class TrainingConfig:
     seed: int = 42
     num_hidden_layers: Optional[int] = None  # override for small tests only
     vocab_size: Optional[int] = None
+    output_dir: Optional[str] = None      # ModelSaver.save_model (train_fp8.py:657-681)
+    load_dir: Optional[str] = None        # local checkpoint directory (from_pretrained_local, te_llama.py:100-178)
 
 
 def create_model(cfg: TrainingConfig, device) -> torch.nn.Module:
@@ -65,7 +68,21 @@ def create_model(cfg: TrainingConfig, device) -> torch.nn.Module:
         torch.set_default_dtype(prev)
     model.to(device)
     model.config.use_cache = False
+    if cfg.load_dir:
+        from . import checkpoint
+        if cfg.use_te:
+            checkpoint.load_into(model, cfg.load_dir, config)
+        else:  # plain HF model: HF-layout shards load by name
+            for shard in checkpoint.resolve_shards(cfg.load_dir):
+                model.load_state_dict(checkpoint.load_shard(shard), strict=False)
+        model.tie_weights()
     return model
+
+
+def save_model(model, cfg: TrainingConfig, layout: str = "hf"):
+    """ModelSaver.save_model (train_fp8.py:657-681) without the tokenizer (unreachable offline): config.json + safetensors."""
+    from . import checkpoint
+    return checkpoint.save_pretrained(checkpoint.unwrap(model), cfg.output_dir, layout=layout, save_fp8_state=True)
 
 
 def prepare_model(model: torch.nn.Module, cfg: TrainingConfig) -> torch.nn.Module:
@@ -172,11 +189,36 @@ def synthetic_batch(cfg: TrainingConfig, vocab_size: int, device, generator=None
     return {"input_ids": ids, "attention_mask": torch.ones_like(ids), "labels": ids.clone()}
 
 
+def _set_first_microbatch(model, value):
+    """`is_first_microbatch` protocol of the TE modules: FP8 weights are cast on the first micro-batch of an accumulation
+    window and reused (w8 / w8T / scale-inverse cached) for the others.  None = cast on every forward (the reference never
+    passes the flag)."""
+    for m in model.modules():
+        if hasattr(m, "_wcache") and hasattr(m, "default_is_first_microbatch"):
+            m.default_is_first_microbatch = value
+
+
 def train_step(model, batch, optimizer, scheduler, cfg: TrainingConfig):
-    """One iteration of Trainer._train_epoch (train_fp8.py:276-291).  Returns the loss tensor (no host sync)."""
-    outputs = model(**batch)
-    loss = outputs.loss
-    loss.backward()
+    """One optimiser step of Trainer._train_epoch (train_fp8.py:276-291).  `batch` is one batch dict or, with
+    gradient_accumulation_steps = N > 1, a list of N micro-batches: loss / N, no gradient exchange on the non-final
+    micro-batches (`no_sync`, train_multi_gpu.py:714-737), FP8 weights cast once per window, one clip + optimiser + LR
+    step at the end.  Returns the (mean) loss tensor (no host sync)."""
+    micro = batch if isinstance(batch, (list, tuple)) else [batch]
+    n = len(micro)
+    total = None
+    for i, mb in enumerate(micro):
+        last = i == n - 1
+        if n > 1:
+            _set_first_microbatch(model, i == 0)
+        ctx = model.no_sync() if (not last and hasattr(model, "no_sync")) else contextlib.nullcontext()
+        with ctx:
+            loss = model(**mb).loss
+            if n > 1:
+                loss = loss / n
+            loss.backward()
+        total = loss.detach() if total is None else total + loss.detach()
+    if n > 1:
+        _set_first_microbatch(model, None)
     if getattr(optimizer, "max_grad_norm", None) is not None:
         pass  # ClippedAdamW: the clip coefficient is folded into the update
     elif hasattr(model, "clip_grad_norm_"):
@@ -186,7 +228,7 @@ def train_step(model, batch, optimizer, scheduler, cfg: TrainingConfig):
     optimizer.step()
     scheduler.step()
     optimizer.zero_grad()
-    return loss
+    return total if n > 1 else loss
 
 
 def setup_distributed():
@@ -235,12 +277,17 @@ def main(argv=None):
     ap.add_argument("--num_hidden_layers", type=int, default=None)
     ap.add_argument("--vocab_size", type=int, default=None)
     ap.add_argument("--num_warmup_steps", type=int, default=100)
+    ap.add_argument("--gradient_accumulation_steps", type=int, default=1)
+    ap.add_argument("--output_dir", default=None, help="save config.json + safetensors (HF parameter names) here after training")
+    ap.add_argument("--load_dir", default=None, help="local checkpoint directory (model.safetensors[.index.json]) to start from")
+    ap.add_argument("--save_layout", choices=["hf", "te"], default="hf")
     ap.add_argument("--repeat_batch", action="store_true", help="debug: train on one fixed synthetic batch")
     a = ap.parse_args(argv)
     cfg = TrainingConfig(model_name=a.model_name, batch_size=a.batch_size, max_seq_length=a.max_seq_length,
                          mixed_precision=a.mixed_precision, fp8_scenario=a.fp8_scenario, use_te=a.use_te,
                          sharding_mode=a.sharding_mode, learning_rate=a.learning_rate,
-                         num_hidden_layers=a.num_hidden_layers, vocab_size=a.vocab_size, num_warmup_steps=a.num_warmup_steps)
+                         num_hidden_layers=a.num_hidden_layers, vocab_size=a.vocab_size, num_warmup_steps=a.num_warmup_steps,
+                         gradient_accumulation_steps=a.gradient_accumulation_steps, output_dir=a.output_dir, load_dir=a.load_dir)
     rank, local, world, device = setup_distributed()
     torch.manual_seed(cfg.seed + rank)
     model = prepare_model(create_model(cfg, device), cfg)
@@ -251,15 +298,20 @@ def main(argv=None):
     fixed = synthetic_batch(cfg, vocab, device) if a.repeat_batch else None
     for step in range(a.num_steps):
         t0 = time.perf_counter()
-        loss = train_step(model, fixed if fixed is not None else synthetic_batch(cfg, vocab, device), opt, sched, cfg)
+        acc = max(1, cfg.gradient_accumulation_steps)
+        batches = [fixed if fixed is not None else synthetic_batch(cfg, vocab, device) for _ in range(acc)]
+        loss = train_step(model, batches if acc > 1 else batches[0], opt, sched, cfg)
         lv = loss.item()
         if not math.isfinite(lv):
             print("Non-finite loss detected, stopping training.")
             break
         dt = time.perf_counter() - t0
         if rank == 0:
-            toks = cfg.batch_size * cfg.max_seq_length * world / dt  # train_multi_gpu.py:751-755
+            toks = cfg.batch_size * cfg.max_seq_length * world * acc / dt  # train_multi_gpu.py:751-755
             print(json.dumps({"step": step, "loss": lv, "ms": dt * 1e3, "tokens_per_s": toks}), flush=True)
+    if cfg.output_dir and rank == 0:
+        files = save_model(model, cfg, a.save_layout)
+        print(json.dumps({"saved": files}), flush=True)
 
 
 if __name__ == "__main__":

@@ -32,6 +32,16 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.mi_abi_version() == _lib.ABI_VERSION
 
 
+def test_abi_version_is_one_number_in_header_library_and_binding():
+    """include/mi_fp8.h `MI_ABI_VERSION` = what the built library reports = what the ctypes binding expects (bumped in round 2:
+    entry points were added in round 1 without a bump)."""
+    from llm_fp8_amd import _lib
+    src = open(os.path.join(ROOT, "include", "mi_fp8.h")).read()
+    m = re.search(r"#define\s+MI_ABI_VERSION\s+(\d+)", src)
+    assert m is not None
+    assert int(m.group(1)) == _lib.load().mi_abi_version() == _lib.ABI_VERSION >= 2
+
+
 def test_argument_errors_are_reported_not_thrown():
     from llm_fp8_amd import _lib
     lib = _lib.load()

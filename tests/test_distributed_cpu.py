@@ -141,8 +141,25 @@ def _arena_worker(rank, world, port, q):
     for p, want in zip(net.parameters(), ref_grads):
         if want is not None:
             err2 = max(err2, float((p.grad - 2 * want).abs().max()))
+    # 3. ranks with DIFFERENT token counts (the reference's collator pads each batch to its own longest sequence, data.py:59-63):
+    #    the row-sparse embedding reduction must gather ragged (ids, rows), not assume its own count for everyone
+    g3 = torch.Generator().manual_seed(11)
+    ragged = [torch.randint(0, 32, (4, 6), generator=g3), torch.randint(0, 32, (3, 10), generator=g3)]
+    ref3 = None
+    for r in range(world):
+        ref.zero_grad()
+        lossf(ref, ragged[r]).backward()
+        gs = [None if p.grad is None else p.grad.clone() for p in ref.parameters()]
+        ref3 = gs if ref3 is None else [a if b is None else a + b for a, b in zip(ref3, gs)]
+    for p in net.parameters():
+        p.grad = None
+    lossf(dp, ragged[rank]).backward()
+    err3 = 0.0
+    for p, want in zip(net.parameters(), ref3):
+        if want is not None:
+            err3 = max(err3, float((p.grad - want / world).abs().max()))
     w0 = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).double().sum().item()
-    q.put((rank, err, aliased and "forward" in net.emb.__dict__, err2, local_only, w0, len(info["buckets"])))
+    q.put((rank, err, aliased and "forward" in net.emb.__dict__, err2, local_only, w0, len(info["buckets"]), err3))
     dist.destroy_process_group()
 
 
@@ -157,8 +174,8 @@ def test_two_rank_gloo_gradient_arena_dp():
     out = sorted(q.get(timeout=300) for _ in range(2))
     [p.join(60) for p in ps]
     assert all(p.exitcode == 0 for p in ps)
-    for rank, err, aliased, err2, local_only, w0, nb in out:
-        assert err < 1e-6 and err2 < 2e-6, (rank, err, err2)
+    for rank, err, aliased, err2, local_only, w0, nb, err3 in out:
+        assert err < 1e-6 and err2 < 2e-6 and err3 < 1e-6, (rank, err, err2, err3)
         assert aliased and nb >= 3
         assert local_only > 1e-4      # the no_sync pass really was rank-local
     assert out[0][5] == out[1][5]     # broadcast: same weights on both ranks

@@ -573,6 +573,52 @@ def test_grad_output_handoffs_are_bitwise_the_unfused_path(te, dev, scenario, mo
     assert torch.equal(h1, h0) and torch.equal(w1, w0)
 
 
+def test_dy_handoff_steps_aside_when_the_gradient_is_observed(te, dev):
+    """module.handoff_readers: `retain_grad()` / a tensor hook on the logits, or anomaly mode, must see the REAL d(logits), not
+    the unwritten placeholder of the cross-entropy -> lm_head hand-off; and the step must equal the no-hand-off step bit for bit."""
+    from llm_fp8_amd import train
+    from llm_fp8_amd.pytorch.fp8 import FP8GlobalStateManager as G
+
+    def run(observe):
+        G.reset()
+        cfg = train.TrainingConfig(model_name="llama-3.2-3b", batch_size=2, max_seq_length=128, mixed_precision="fp8",
+                                   fp8_scenario="default", use_te=True, sharding_mode="none", num_hidden_layers=1, vocab_size=2048,
+                                   learning_rate=1e-3, num_warmup_steps=0)
+        torch.manual_seed(5)
+        device = torch.device(dev)
+        model = train.prepare_model(train.create_model(cfg, device), cfg)
+        model.train()
+        batch = train.synthetic_batch(cfg, 2048, device, torch.Generator(device=device).manual_seed(2))
+        out = model(**batch)
+        seen = {}
+        if observe == "retain":
+            out.logits.retain_grad()
+        elif observe == "hook":
+            out.logits.register_hook(lambda g: seen.__setitem__("g", g.clone()))
+        if observe == "anomaly":
+            with torch.autograd.detect_anomaly(check_nan=True):
+                out.loss.backward()
+        else:
+            out.loss.backward()
+        g = out.logits.grad if observe == "retain" else seen.get("g")
+        w = model.lm_head.weight.grad.clone()
+        return g, w
+
+    try:
+        import os
+        os.environ["LLM_FP8_AMD_NO_DY_HANDOFF"] = "1"
+        g_ref, w_ref = run("hook")          # ordinary route: the true d(logits)
+        del os.environ["LLM_FP8_AMD_NO_DY_HANDOFF"]
+        for mode in ("retain", "hook", "anomaly", None):
+            g, w = run(mode)
+            assert torch.equal(w, w_ref), mode   # same lm_head wgrad whichever route
+            if mode in ("retain", "hook"):
+                assert g is not None and torch.equal(g, g_ref), mode
+    finally:
+        os.environ.pop("LLM_FP8_AMD_NO_DY_HANDOFF", None)
+        G.reset()
+
+
 def test_local_embedding_grad_rows_added_in_place(te, dev):
     """distributed.install_local_embedding_grad (what train.wrap_distributed does without a wrapper): the tied table's gradient
     = lm_head wgrad + embedding rows, the rows added in place; against autograd's dense route on the same model and batch."""

@@ -173,6 +173,39 @@ def main():
                     lo = base - 12
                     print(f"   boundary into tile {ti}, K-tiles nk-3 .. +2, per phase [load/wait seg | mfma seg]: "
                           + "  ".join((("|| " if (x - base) % 4 == 0 else "") + f"{int(load_seg[x - 1])}/{int(mfma_seg[x])}") for x in range(lo, base + 12)), flush=True)
+    if "abbase" in args.which:  # same-process A/B of the current library against a saved build (default: the round-1 library)
+        import ctypes
+        from llm_fp8_amd import _lib
+        cur = _lib.load()
+        base_path = os.environ.get("MI_BASE_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "libmi_fp8_r1.so"))
+        base = ctypes.CDLL(base_path)
+        for lib_ in (base,):
+            lib_.mi_gemm_fp8.argtypes = cur.mi_gemm_fp8.argtypes
+            lib_.mi_gemm_fp8.restype = ctypes.c_int
+        st = torch.cuda.current_stream().cuda_stream
+        models = {"3b": (8192, {"qkv": (5120, 3072), "o": (3072, 3072), "fc1": (16384, 3072), "fc2": (3072, 8192)}),
+                  "1b": (8192, {"qkv": (3072, 2048), "o": (2048, 2048), "fc1": (16384, 2048), "fc2": (2048, 8192)}),
+                  "8b": (6144, {"qkv": (6144, 4096), "o": (4096, 4096), "fc1": (28672, 4096), "fc2": (4096, 14336)})}
+        tot = {}
+        for mname in os.environ.get("MODELS", "3b").split(","):
+            M, sites = models[mname]
+            tb = tc = 0.0
+            for name, (N, K) in sites.items():
+                for kind, (m, n, k) in (("fprop", (M, N, K)), ("dgrad", (M, K, N)), ("wgrad", (N, K, M))):
+                    a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
+                    out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+                    def mk(lib_):
+                        def f():
+                            rc = lib_.mi_gemm_fp8(a.data_ptr(), b.data_ptr(), out.data_ptr(), one.data_ptr(), one.data_ptr(), None,
+                                                  m, n, k, k, k, n, 0, 0, 0, 4, st)
+                            assert rc == 0
+                        return f
+                    res = time_interleaved({"base": mk(base), "cur": mk(cur)}, rounds=10, inner=5)
+                    tb += res["base"]; tc += res["cur"]
+                    fl = 2.0 * m * n * k
+                    print(f"abbase {mname} {name:4s} {kind:5s} {m}x{n}x{k}: base {res['base']*1e6:7.1f} us {fl/res['base']/1e12:6.0f} TF   cur {res['cur']*1e6:7.1f} us "
+                          f"{fl/res['cur']/1e12:6.0f} TF   {res['base']/res['cur']:.3f}x", flush=True)
+            print(f"abbase {mname} decoder-layer GEMM time: base {tb*1e6:8.1f} us  cur {tc*1e6:8.1f} us  {tb/tc:.3f}x", flush=True)
     if "clock" in args.which:
         from llm_fp8_amd import _lib
         lib = _lib.load()
