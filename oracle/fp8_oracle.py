@@ -365,6 +365,96 @@ def dswiglu_f32(h_bits: np.ndarray, dact_bits: np.ndarray) -> np.ndarray:
     return np.concatenate([d * u * (s * (1.0 + g * (1.0 - s))), d * (g * s)], axis=1).astype(np.float32)
 
 
+# Device-order float32 restatements of the fused front ends (the kernels' arithmetic is
+# llm_fp8_amd/csrc/mi_fused.hip: swiglu_cast_kernel, norm_cast_kernel, rmsnorm_stats_kernel).  Same operations in the same
+# order, every one rounded to float32 (numpy float32 arithmetic is IEEE per operation; the kernels are compiled with
+# -ffp-contract=off, so no FMA contraction).  What can still differ from the device is the transcendental alone: `__expf`
+# (v_exp_f32 of x * log2 e) and `rsqrtf` (v_rsq_f32) are accurate to a few ulps, numpy's exp / sqrt to <= 1 ulp.  The FP8
+# bytes of the fused kernels therefore equal the bytes of these values except where the value lies within a few float32
+# ulps of an FP8 rounding boundary -- the property tests/test_kernels_gpu.py asserts (fp8_mismatches_near_boundary).
+def swiglu_f32_device_order(h_bits: np.ndarray) -> np.ndarray:
+    """(g * sigmoid(g)) * u with sigmoid(g) = 1 / (1 + exp(-g)), all float32, left to right as in swiglu_cast_kernel MODE 0."""
+    h = bf16_bits_to_f32(h_bits)
+    f = h.shape[1] // 2
+    g, u = h[:, :f], h[:, f:]
+    one = np.float32(1.0)
+    with np.errstate(over="ignore"):
+        sg = one / (one + np.exp(-g, dtype=np.float32))
+    return ((g * sg) * u).astype(np.float32)
+
+
+def dswiglu_f32_device_order(h_bits: np.ndarray, dact_bits: np.ndarray) -> np.ndarray:
+    """[(d * u) * (sg * (1 + g * (1 - sg))) | d * (g * sg)] in float32, the grouping of swiglu_cast_kernel MODE 1."""
+    h = bf16_bits_to_f32(h_bits)
+    d = bf16_bits_to_f32(dact_bits)
+    f = h.shape[1] // 2
+    g, u = h[:, :f], h[:, f:]
+    one = np.float32(1.0)
+    with np.errstate(over="ignore"):
+        sg = one / (one + np.exp(-g, dtype=np.float32))
+    left = (d * u) * (sg * (one + g * (one - sg)))
+    right = d * (g * sg)
+    return np.concatenate([left, right], axis=1).astype(np.float32)
+
+
+def rmsnorm_sumsq_device_order(x_bits: np.ndarray) -> np.ndarray:
+    """Row sums of squares in the order of rmsnorm_stats_kernel: lane l (of 64) walks columns 8 l + 512 t, adds
+    (a*a + b*b) for its 4 bf16 pairs in turn, then the 64 partial sums meet in a butterfly (xor 32, 16, 8, 4, 2, 1)."""
+    x = bf16_bits_to_f32(x_bits)
+    rows, cols = x.shape
+    assert cols % 8 == 0
+    pad = (-cols) % 512
+    if pad:
+        x = np.concatenate([x, np.zeros((rows, pad), np.float32)], axis=1)  # lanes past the row end simply do not iterate
+    xt = x.reshape(rows, -1, 64, 4, 2)                                       # [row, t, lane, pair, (a, b)]
+    acc = np.zeros((rows, 64), np.float32)
+    for t in range(xt.shape[1]):
+        valid = (np.arange(64) * 8 + 512 * t) < cols
+        for j in range(4):
+            a, b = xt[:, t, :, j, 0], xt[:, t, :, j, 1]
+            term = (a * a + b * b).astype(np.float32)
+            acc = np.where(valid[None, :], (acc + term).astype(np.float32), acc)
+    for o in (32, 16, 8, 4, 2, 1):
+        acc = (acc + acc[:, np.arange(64) ^ o]).astype(np.float32)
+    return acc[:, 0]
+
+
+def rmsnorm_rstd_device_order(x_bits: np.ndarray, eps: float) -> np.ndarray:
+    """1 / sqrt(sumsq / cols + eps) in float32 (the device uses v_rsq_f32: equal up to its 1-2 ulp approximation error)."""
+    ss = rmsnorm_sumsq_device_order(x_bits)
+    cols = np.float32(x_bits.shape[1])
+    return (np.float32(1.0) / np.sqrt((ss / cols + np.float32(eps)).astype(np.float32))).astype(np.float32)
+
+
+def norm_apply_f32_device_order(x_bits: np.ndarray, rstd_f32: np.ndarray, gamma_bits: np.ndarray) -> np.ndarray:
+    """(x * rstd[row]) * gamma[col] in float32, the grouping of norm_cast_kernel: no transcendental, so with the device's own
+    rstd as input the fused kernel's FP8 bytes must equal the bytes of this value exactly."""
+    x = bf16_bits_to_f32(x_bits)
+    g = bf16_bits_to_f32(gamma_bits)
+    return ((x * rstd_f32.astype(np.float32)[:, None]).astype(np.float32) * g[None, :]).astype(np.float32)
+
+
+def fp8_mismatches_near_boundary(got_bytes: np.ndarray, v_scaled_f32: np.ndarray, fmt: int, rel: float = 2.0 ** -17):
+    """For FP8 bytes produced from a float32 value that may differ from `v_scaled_f32` by a few ulps: returns
+    (n_mismatch, n_unexplained) where a mismatch is EXPLAINED when the two codes are neighbours and `v_scaled_f32` lies within
+    `rel` (relative) of the rounding boundary between them (the midpoint of the two FP8 values; the saturation edge counts)."""
+    want = fp8_encode_sat(v_scaled_f32.astype(np.float32), fmt)
+    got = np.asarray(got_bytes)
+    both_zero = ((got & 0x7F) == 0) & ((want & 0x7F) == 0)
+    mism = (got != want) & ~both_zero
+    if not mism.any():
+        return 0, 0
+    tab = fp8_decode_table(fmt).astype(np.float64)
+    gv, wv = tab[got[mism]], tab[want[mism]]
+    v = v_scaled_f32[mism].astype(np.float64)
+    neighbours = np.abs((got[mism].astype(np.int16) & 0x7F) - (want[mism].astype(np.int16) & 0x7F)) == 1
+    same_sign = ((got[mism] ^ want[mism]) & 0x80) == 0
+    mid = 0.5 * (gv + wv)
+    near = np.abs(v - mid) <= rel * np.maximum(np.abs(mid), 1e-30)
+    explained = neighbours & same_sign & near & np.isfinite(mid)
+    return int(mism.sum()), int((~explained).sum())
+
+
 def rope_f32(x_bits: np.ndarray, pos: np.ndarray, head_dim: int, base: float = 10000.0, conj: bool = False) -> np.ndarray:
     """TE-style non-interleaved RoPE on [T, heads*D] (row t at position pos[t]); float32 math, one bf16 rounding."""
     x = bf16_bits_to_f32(x_bits).astype(np.float64)
