@@ -27,17 +27,18 @@ sys.path.insert(0, ROOT)
 FP8_DENSE_PEAK_TFLOPS = 5000.0  # MI355X dense FP8 MFMA peak (MI355X_MICROARCH.md: ~5 PF dense)
 
 
-def cpu_baseline(model_name: str, seq: int = 128, layers=(2, 4), timed_steps: int = 2):
-    """Reference's no-TE HF bf16 path (train_fp8.py:118-124 model, :270-291 step) on the host CPUs.
-    Bounded sample: full widths, batch 1 x `seq` tokens, two reduced depths, extrapolated linearly in depth."""
+def cpu_baseline(bench_model: str, seq: int = 128, timed_steps: int = 3, extrapolate_bench_model: bool = False):
+    """SURVEY.md 8d "CPU baseline (same run)": the repo's own no-TE HF bf16 path (train_fp8.py:118-124 model, :270-291 step) on
+    the host CPUs -- BASELINE.json config #1: Llama-3.2-1B at FULL depth (16 layers), batch 1 x seq 128, 1 warm-up + 3 timed
+    optimiser steps, tokens/s = 128 / step time.  No extrapolation.  Plus the Linear-level micro-baseline: `F.linear` bf16
+    fprop + dgrad + wgrad on the CPU for every GEMM site of the benchmarked model at M = 128."""
     from llm_fp8_amd import llama, train
     from transformers.models.llama.modeling_llama import LlamaForCausalLM
-    full_layers = llama.llama_config(model_name).num_hidden_layers
-    times = {}
-    for L in layers:
+
+    def time_model(model_name, layers, steps):
         cfg = train.TrainingConfig(model_name=model_name, batch_size=1, max_seq_length=seq, mixed_precision="bf16",
-                                   use_te=False, num_hidden_layers=L, num_warmup_steps=0)
-        config = llama.llama_config(model_name, num_hidden_layers=L)
+                                   use_te=False, num_hidden_layers=layers, num_warmup_steps=0)
+        config = llama.llama_config(model_name, **({} if layers is None else {"num_hidden_layers": layers}))
         torch.manual_seed(42)
         prev = torch.get_default_dtype()
         torch.set_default_dtype(torch.bfloat16)
@@ -49,21 +50,105 @@ def cpu_baseline(model_name: str, seq: int = 128, layers=(2, 4), timed_steps: in
         opt, sched = train.create_optimizer(model, cfg)
         batch = train.synthetic_batch(cfg, config.vocab_size, torch.device("cpu"))
         train.train_step(model, batch, opt, sched, cfg)  # warm-up
-        t0 = time.perf_counter()
-        for _ in range(timed_steps):
+        per = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
             train.train_step(model, batch, opt, sched, cfg)
-        times[L] = (time.perf_counter() - t0) / timed_steps
+            per.append(time.perf_counter() - t0)
         del model, opt, sched
-    l0, l1 = layers
-    per_layer = max((times[l1] - times[l0]) / (l1 - l0), 0.0)
-    fixed = max(times[l0] - l0 * per_layer, 0.0)
-    t_full = fixed + full_layers * per_layer
-    return {
-        "value": seq / t_full, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": (f"HF LlamaForCausalLM bf16 (no TE), {model_name} widths, fwd+bwd+clip+AdamW, batch 1 x seq {seq}; "
-                   f"timed at {l0} and {l1} of {full_layers} layers ({times[l0]:.2f}s, {times[l1]:.2f}s per step) and "
-                   f"extrapolated linearly in depth to {t_full:.2f}s per step; host has {os.cpu_count()} logical CPUs"),
+        return per
+
+    per = time_model("llama-3.2-1b", None, timed_steps)
+    t_step = sum(per) / len(per)
+    out = {
+        "value": seq / t_step, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": (f"BASELINE.json config #1: HF LlamaForCausalLM bf16 (no TE, sdpa), Llama-3.2-1B at full depth (16 layers), "
+                   f"fwd+bwd+clip+AdamW, batch 1 x seq {seq}, 1 warm-up + {timed_steps} timed steps "
+                   f"({', '.join(f'{t:.2f}' for t in per)} s); torch.get_num_threads() = {torch.get_num_threads()}, "
+                   f"os.cpu_count() = {os.cpu_count()}"),
+        "linear_sites": linear_micro_baseline(bench_model),
     }
+    if extrapolate_bench_model and bench_model != "llama-3.2-1b":  # optional extra (round 1's figure): the benchmarked model, by depth
+        full = llama.llama_config(bench_model).num_hidden_layers
+        t2, t4 = (sum(x) / len(x) for x in (time_model(bench_model, 2, 2), time_model(bench_model, 4, 2)))
+        per_layer = max((t4 - t2) / 2, 0.0)
+        t_full = max(t2 - 2 * per_layer, 0.0) + full * per_layer
+        out["extrapolated_bench_model"] = {"tokens/s": seq / t_full, "note": f"{bench_model}: timed at 2 and 4 of {full} layers, linear in depth"}
+    return out
+
+
+def linear_micro_baseline(model_name: str, M: int = 128, iters: int = 3):
+    """`F.linear` bf16 forward + dgrad + wgrad on the host CPUs for each GEMM site of `model_name` at M = 128 tokens
+    (BASELINE.md section 3 / SURVEY.md 8d): the per-site counterpart of the GPU `gemm_sites` table."""
+    import torch.nn.functional as F
+    from llm_fp8_amd import llama
+    c = llama.llama_config(model_name)
+    hd = getattr(c, "head_dim", None) or c.hidden_size // c.num_attention_heads
+    sites = {"qkv": ((c.num_attention_heads + 2 * c.num_key_value_heads) * hd, c.hidden_size),
+             "o_proj": (c.hidden_size, c.num_attention_heads * hd),
+             "fc1": (2 * c.intermediate_size, c.hidden_size), "fc2": (c.hidden_size, c.intermediate_size),
+             "lm_head": (c.vocab_size, c.hidden_size)}
+    res = {}
+    g = torch.Generator().manual_seed(0)
+    for name, (N, K) in sites.items():
+        x = torch.randn(M, K, generator=g).to(torch.bfloat16).requires_grad_(True)
+        w = (torch.randn(N, K, generator=g) * 0.02).to(torch.bfloat16).requires_grad_(True)
+        dy = (torch.randn(M, N, generator=g) / 32).to(torch.bfloat16)
+        F.linear(x, w).backward(dy)  # warm-up
+        ts = []
+        for _ in range(iters):
+            x.grad = w.grad = None
+            t0 = time.perf_counter()
+            F.linear(x, w).backward(dy)
+            ts.append(time.perf_counter() - t0)
+        t = min(ts)
+        res[name] = {"shape_MxNxK": f"{M}x{N}x{K}", "ms_fwd_dgrad_wgrad": t * 1e3, "GFLOP/s": 6.0 * M * N * K / t / 1e9}
+    return res
+
+
+def gemm_clock_probe(sites, top: int = 4):
+    """In-kernel clock of the FP8 GEMM (MI355X_MICROARCH.md "DVFS give-back" item 6): the stamped diagnostic build (algo 21)
+    reports d(s_memtime) / d(s_memrealtime) x 100 MHz around each workgroup's whole tile walk; run after >= 1 s of back-to-back
+    launches of the production kernel on random FP8 bytes, for the `top` sites by time, time-weighted."""
+    from llm_fp8_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    st = torch.cuda.current_stream().cuda_stream
+    one = torch.ones(1, device=dev)
+    g = torch.Generator(device=dev).manual_seed(0)
+    tot_w = tot = 0.0
+    per_site = {}
+    for tag, v in sorted(sites.items(), key=lambda kv: -kv[1]["seconds"])[:top]:
+        m, n, k = (int(t) for t in tag.split("x"))
+        if (m % 256 and m % 192) or (n % 256 and n % 192) or k % 256 or m * k >= 2 ** 31 or n * k >= 2 ** 31 or m * n * 2 >= 2 ** 31:
+            continue
+        a = torch.randint(0, 256, (m, k), generator=g, device=dev, dtype=torch.uint8)
+        b = torch.randint(0, 256, (n, k), generator=g, device=dev, dtype=torch.uint8)
+        a[(a & 0x7F) >= 0x78] &= 0x3F
+        b[(b & 0x7F) >= 0x78] &= 0x3F
+        out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+        dbg = torch.zeros((256, 4), dtype=torch.int64, device=dev)
+
+        def run(algo, ptr):
+            rc = lib.mi_gemm_fp8(a.data_ptr(), b.data_ptr(), out.data_ptr(), one.data_ptr(), one.data_ptr(), ptr, m, n, k, k, k, n, 0, 0, 0, algo, st)
+            assert rc == 0, lib.mi_last_error()
+
+        t0 = time.time()
+        while time.time() - t0 < 1.0:
+            for _ in range(40):
+                run(4, None)
+            torch.cuda.synchronize()
+        run(21, dbg.data_ptr())
+        torch.cuda.synchronize()
+        d = dbg.cpu().double()
+        d = d[d[:, 1] > 0]
+        if d.numel() == 0:
+            continue
+        clk = float((d[:, 0] / d[:, 1] * 100.0).median()) / 1e3  # GHz
+        per_site[tag] = clk
+        tot_w += v["seconds"]
+        tot += v["seconds"] * clk
+    return (tot / tot_w if tot_w else None), per_site
 
 
 def pmc_traffic(by_tag):
@@ -96,6 +181,9 @@ def main():
     ap.add_argument("--scenario", default="default", choices=["default", "hybrid", "mxfp8"])
     ap.add_argument("--sharding_mode", default="auto")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result is then not the headline metric)")
+    ap.add_argument("--route", default="fused", choices=["fused", "reference"],
+                    help="reference = drive every decoder layer exactly as te_llama.py:76-81 does (public kwargs, plain residual adds)")
+    ap.add_argument("--cpu-baseline-extrapolate", action="store_true", help="also time the benchmarked model at 2 and 4 layers on the CPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -113,6 +201,9 @@ def main():
                                mixed_precision="fp8", fp8_scenario=args.scenario, use_te=True,
                                sharding_mode=args.sharding_mode, num_hidden_layers=args.layers)
     torch.manual_seed(cfg.seed)  # same weights on every rank; data differs per rank below
+    if args.route == "reference":
+        from llm_fp8_amd import llama as _llama
+        _llama.TELlamaDecoderLayer.route = "reference"
     model = train.prepare_model(train.create_model(cfg, device), cfg)
     vocab = model.config.vocab_size
     n_layers = model.config.num_hidden_layers
@@ -129,13 +220,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    aux_timer = KernelTimer(kinds=("cast_amax", "mxfp8_quantize", "attn_fwd", "attn_bwd"))  # informational, outside the timed region
+    # the HBM-bound kernels (casts, block quantisers) and attention are bracketed during ONE step of the timed region (an odd one:
+    # the even steps carry the GEMM events)
+    aux_timer = KernelTimer(kinds=("cast_amax", "mxfp8_quantize", "attn_fwd", "attn_bwd"))
+    aux_step = 1 if args.steps > 1 else -1
     for i in range(args.warmup):
-        if i == args.warmup - 1 and not args.no_kernel_timing:
-            with aux_timer.install():
-                train.train_step(model, batches[i % 4], opt, sched, cfg)
-        else:
-            train.train_step(model, batches[i % 4], opt, sched, cfg)
+        train.train_step(model, batches[i % 4], opt, sched, cfg)
     # inside the timed region only the FP8 GEMM launches are bracketed by HIP events (every event costs queue time)
     timer = KernelTimer(kinds=("gemm_fp8", "gemm_mxfp8"))
     sync()
@@ -147,6 +237,9 @@ def main():
         for i in range(args.steps):
             if i % 2 == 0:  # GEMM launches of every other timed step carry HIP events (each event costs ~4.5 us of queue time)
                 with timer.install():
+                    loss = train.train_step(model, batches[i % 4], opt, sched, cfg)
+            elif i == aux_step:
+                with aux_timer.install():
                     loss = train.train_step(model, batches[i % 4], opt, sched, cfg)
             else:
                 loss = train.train_step(model, batches[i % 4], opt, sched, cfg)
@@ -168,7 +261,7 @@ def main():
             "config": {"workload": (f"{args.model} ({n_layers} layers) full fine-tuning step, batch {args.batch}/GPU x seq {args.seq}, "
                                      f"fp8_scenario={args.scenario} (te_llama counterpart, lm_head FP8 under the outer recipe), "
                                      "random-init weights, synthetic tokens"),
-                       "global_batch": args.batch * world, "seq_len": args.seq,
+                       "route": args.route, "global_batch": args.batch * world, "seq_len": args.seq,
                        "parallelism": "single" if resolved_mode == "none" else
                        f"dp{world} {resolved_mode}" + (" (gradient arena, bucketed RCCL all-reduce)" if resolved_mode == "replicated" else "")},
             "final_loss": loss_val,
@@ -193,8 +286,20 @@ def main():
                     sites[tag] = {"tflops": v["work"] / v["seconds"] / 1e12, "us": v["seconds"] / v["launches"] * 1e6,
                                   "launches_per_step": v["launches"] / ((args.steps + 1) // 2)}
                 out["gemm_sites"] = sites
+                if world == 1 and kind == "gemm_fp8":
+                    try:
+                        clk, per_site = gemm_clock_probe(g["by_tag"])
+                    except Exception as e:  # a diagnostic must never cost the headline line
+                        clk, per_site = None, {"error": str(e)}
+                    if clk:
+                        out["roofline"]["clock_ghz"] = clk
+                        out["roofline"]["frac_at_clock"] = achieved / (FP8_DENSE_PEAK_TFLOPS * clk / 2.4)
+                        out["roofline"]["clock_note"] = ("in-kernel clock of the GEMM on random FP8 bytes: stamped build (algo 21), d(s_memtime)/d(s_memrealtime), "
+                                                         "median over workgroups after 1 s of back-to-back launches, time-weighted over the top sites: "
+                                                         + ", ".join(f"{t} {c:.2f} GHz" for t, c in per_site.items())
+                                                         + "; frac_at_clock = achieved / (5000 TFLOP/s x clock / 2.4 GHz)")
             hbm = {}
-            aux = aux_timer.summarize()  # one warm-up step, not part of the timed region
+            aux = aux_timer.summarize()  # one step of the timed region
             for k in ("cast_amax", "mxfp8_quantize"):
                 if k in aux and aux[k]["seconds"] > 0:
                     hbm[k] = {"GB/s": aux[k]["bytes"] / aux[k]["seconds"] / 1e9, "ms_per_step": aux[k]["seconds"] * 1e3,
@@ -204,11 +309,12 @@ def main():
                     hbm[k] = {"TFLOP/s": aux[k]["work"] / aux[k]["seconds"] / 1e12, "ms_per_step": aux[k]["seconds"] * 1e3,
                               "launches_per_step": aux[k]["launches"]}
             out["hbm_kernels"] = hbm
-            out["hbm_kernels_note"] = "cast / quantise / attention kernels bracketed during the last warm-up step only"
+            out["hbm_kernels_note"] = ("cast / quantise / attention kernels bracketed by HIP events during timed step 1 (of the timed region); "
+                                       "PMC FETCH_SIZE / WRITE_SIZE of the same kernels: profiles/*_hbm_pmc_traffic.json")
         if world == 1 and not args.no_cpu_baseline:
             del model, opt
             torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(args.model)
+            out["cpu_baseline"] = cpu_baseline(args.model, extrapolate_bench_model=args.cpu_baseline_extrapolate)
         print(json.dumps(out), flush=True)
     if dist.is_available() and dist.is_initialized():
         if world > 1:

@@ -316,12 +316,12 @@ def _ulp_close_fp8(got, want, fmt, frac_exact=0.995):
     assert (diff == 0).mean() >= frac_exact, f"only {(diff == 0).mean():.4f} exact"
 
 
-def _assert_matches_fp32_restatement(got_bytes, v_scaled_f32, fmt, what, max_frac=1e-3):
+def _assert_matches_fp32_restatement(got_bytes, v_scaled_f32, fmt, what, max_frac=1e-3, abs_slack=None):
     """The device computed the same float32 operations in the same order as the oracle's *_device_order restatement; only its
     transcendental (v_exp_f32 / v_rsq_f32, a few ulps) can differ from numpy's.  So the FP8 bytes are identical EXCEPT where the
     float32 value lies within 2^-17 (relative) of the rounding boundary between two neighbouring codes -- every mismatch must be
     explained that way, and there can only be a handful (a boundary band of 2^-17 against a code spacing of 2^-4 .. 2^-2)."""
-    n_mis, n_bad = O.fp8_mismatches_near_boundary(got_bytes, v_scaled_f32, fmt)
+    n_mis, n_bad = O.fp8_mismatches_near_boundary(got_bytes, v_scaled_f32, fmt, abs_slack=abs_slack)
     assert n_bad == 0, f"{what}: {n_bad} of {n_mis} mismatching bytes are NOT within 2^-17 of a rounding boundary"
     assert n_mis <= max(2, max_frac * got_bytes.size), f"{what}: {n_mis} of {got_bytes.size} bytes differ"
 
@@ -358,7 +358,11 @@ def test_dswiglu_cast_vs_oracle(ops, dev, shape):
     want = O.fp8_encode_sat((dh * scale).astype(np.float32), O.E5M2)
     _ulp_close_fp8(u8(y), want, O.E5M2)
     dh32 = O.dswiglu_f32_device_order(bf16_bits(h), bf16_bits(d))
-    _assert_matches_fp32_restatement(u8(y), (dh32 * scale).astype(np.float32), O.E5M2, "dswiglu_cast")
+    # dsilu(g) = s (1 + g (1 - s)) vanishes near g = -1.2785: around that zero the result is the difference of two O(1) terms and
+    # carries a few float32 ulps OF THOSE TERMS (times |d u|), however small it is itself -> absolute slack 2^-21 |d u| scale there
+    hf, df = O.bf16_bits_to_f32(bf16_bits(h)), O.bf16_bits_to_f32(bf16_bits(d))
+    slack = np.concatenate([np.abs(df * hf[:, F:]) * scale * 2.0 ** -21, np.zeros_like(df)], axis=1)
+    _assert_matches_fp32_restatement(u8(y), (dh32 * scale).astype(np.float32), O.E5M2, "dswiglu_cast", abs_slack=slack)
     np.testing.assert_array_equal(u8(yT), u8(y).T)
     np.testing.assert_allclose(amax.item(), np.abs(dh).max(), rtol=1e-5)
     np.testing.assert_allclose(cs.sum(0).cpu().numpy(), dh.astype(np.float64).sum(0), rtol=1e-4, atol=1e-4 * np.abs(dh).max() * np.sqrt(R))

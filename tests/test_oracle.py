@@ -147,3 +147,34 @@ def test_delayed_linear_oracle_runs_three_steps():
     ref = xf @ wf.T
     err = np.linalg.norm(O.bf16_bits_to_f32(y) - ref) / np.linalg.norm(ref)
     assert err < 0.08, err
+
+
+def test_device_order_restatements_agree_with_the_float64_ones():
+    """The float32, kernel-order restatements of the fused front ends (used to pin the fused kernels byte for byte except at
+    rounding boundaries) are the same functions as the float64 ones, to float32 accuracy."""
+    rng = np.random.default_rng(5)
+    h = O.f32_to_bf16_bits((rng.normal(size=(64, 256)) * 2).astype(np.float32))
+    d = O.f32_to_bf16_bits((rng.normal(size=(64, 128)) / 8).astype(np.float32))
+    a, b = O.swiglu_f32_device_order(h), O.swiglu_f32(h)
+    assert np.all(np.abs(a - b) <= 4e-6 * np.maximum(np.abs(b), 1e-3))
+    a, b = O.dswiglu_f32_device_order(h, d), O.dswiglu_f32(h, d)
+    assert np.all(np.abs(a - b) <= 1e-5 * np.maximum(np.abs(b), 1e-3))
+    x = O.f32_to_bf16_bits((rng.normal(size=(9, 1032)) * np.exp(rng.normal(size=(9, 1)))).astype(np.float32))  # 1032: a ragged last sweep
+    gam = O.f32_to_bf16_bits((rng.random(1032) + 0.5).astype(np.float32))
+    y64, rstd64 = O.rmsnorm_f32(x, gam, 1e-5)
+    rstd32 = O.rmsnorm_rstd_device_order(x, 1e-5)
+    np.testing.assert_allclose(rstd32, rstd64, rtol=1e-6)
+    y32 = O.norm_apply_f32_device_order(x, rstd32, gam)
+    np.testing.assert_allclose(y32, y64, rtol=2e-6, atol=1e-7)
+
+
+def test_fp8_mismatch_classifier():
+    v = np.array([1.0, 17.0, 17.0, 17.0, 98.0], np.float32)  # 17 is the midpoint of the E4M3 codes 16 and 18
+    want = O.fp8_encode_sat(v, O.E4M3)
+    got = want.copy()
+    assert O.fp8_mismatches_near_boundary(got, v, O.E4M3) == (0, 0)
+    got[1] = O.fp8_encode_sat(np.array([18.0], np.float32), O.E4M3)[0]   # neighbour code, value ON the boundary: explained
+    assert O.fp8_mismatches_near_boundary(got, v, O.E4M3) == (1, 0)
+    got[4] = O.fp8_encode_sat(np.array([104.0], np.float32), O.E4M3)[0]  # neighbour code of 96 (98 -> 96), but 98 is no boundary (100 is)
+    assert O.fp8_mismatches_near_boundary(got, v, O.E4M3) == (2, 1)
+    assert O.fp8_mismatches_near_boundary(got, v, O.E4M3, abs_slack=np.full(5, 10.0)) == (2, 0)
