@@ -278,6 +278,20 @@ int mi_adamw_bf16_multi(const int64_t* table, int n_tensors, const int32_t* chun
                         const float* grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay,
                         int64_t step, void* stream);
 /*
+ * mi_adamw_bf16_multi that ALSO emits the FP8 copies the next forward would cast (K1/K2 folded into the optimiser pass).
+ * table: int64 [12, n_tensors]: rows 0-4 as above (p, g, exp_avg, exp_avg_sq, numel), then per tensor
+ *   5 cols (0 = no FP8 sink: flat chunks of chunk_elems; > 0: the tensor is a [numel / cols, cols] weight and its chunks are
+ *     128 x 128 tiles, chunk index = tile_row * ceil(cols / 128) + tile_col),
+ *   6 y (fp8 [rows, ld_y] or 0), 7 yT (fp8 [cols, ld_yT] or 0), 8 ld_y, 9 ld_yT, 10 const float* scale, 11 float* amax (or 0).
+ * For a sink tensor every element is updated, rounded to bf16 and stored, and that rounded value is quantised exactly as
+ * mi_cast_amax would: y = sat_cast_e4m3(float(bf16) * *scale), *amax = max(*amax, |bf16|) -- bitwise the bytes of a
+ * mi_cast_amax call on the updated weight.  rows and cols multiples of 8.
+ */
+int mi_adamw_cast_bf16_multi(const int64_t* table, int n_tensors, const int32_t* chunks, int n_chunks, int chunk_elems,
+                             const float* grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay,
+                             int64_t step, void* stream);
+
+/*
  * Embedding weight gradient added in place: grad[id, :] += alpha * sum_{tokens t with ids[t] == id} dY[t, :]   (bf16, fp32
  * sums).  The tied lm_head / embedding table of the reference's Llama models (te_llama.py: `tie_word_embeddings`) already
  * holds the lm_head wgrad when the embedding's backward runs; this replaces a dense [vocab, hidden] scatter + add by a pass

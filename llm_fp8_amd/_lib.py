@@ -42,6 +42,8 @@ SIGNATURES = {
     "mi_sumsq_bf16_multi": [_p, _c_int, _p, _c_int, _c_int, _p, _p],
     "mi_adamw_bf16_multi": [_p, _c_int, _p, _c_int, _c_int, _p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                             ctypes.c_float, _c_i64, _p],
+    "mi_adamw_cast_bf16_multi": [_p, _c_int, _p, _c_int, _c_int, _p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                 ctypes.c_float, _c_i64, _p],
     "mi_embedding_grad_add": [_p, _p, _p, _p, _c_i64, _c_i64, _c_i64, ctypes.c_float, _c_i64, _p],
     "mi_adamw_bf16": [_p, _p, _p, _p, _c_i64, _p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                       ctypes.c_float, _c_i64, _p],

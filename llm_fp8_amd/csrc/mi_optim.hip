@@ -215,6 +215,140 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const int64_t* __restr
   }
 }
 
+// AdamW + FP8 weight cast in one pass (the weight-cast hand-off): under delayed scaling the scale the NEXT
+// forward quantises a weight with is already final when the optimiser runs (the forward arena was updated at the end of this
+// step's forward), and the optimiser streams every weight anyway.  For tensors with a "sink" (cols > 0) the chunk is a 128 x 128
+// tile of the [rows, cols] weight (the tiling of cast_amax_kernel: 8 x 8 block per lane, in-register byte transpose): each
+// element is updated, rounded to bf16, stored -- and that ROUNDED value is quantised exactly as mi_cast_amax would
+// (y = sat(float(bf16) * scale), amax = max |bf16|), into y [rows, ld_y] and the transposed copy yT [cols, ld_yT].
+// Tensors without a sink (cols == 0) take the flat path of adamw_multi_kernel.  Table rows (int64 each, T columns):
+//   0 p  1 g  2 exp_avg  3 exp_avg_sq  4 numel  5 cols  6 y  7 yT  8 ld_y  9 ld_yT  10 scale ptr  11 amax ptr
+__global__ __launch_bounds__(256) void adamw_cast_multi_kernel(const int64_t* __restrict__ tab, int T, const ChunkRef* __restrict__ chunks,
+                                                               int chunk_elems, const float* __restrict__ grad_scale, AdamArgs a) {
+  __shared__ float s_amax[4];
+  const ChunkRef cr = chunks[blockIdx.x];
+  uint16_t* p = reinterpret_cast<uint16_t*>(tab[cr.tensor]);
+  const uint16_t* g = reinterpret_cast<const uint16_t*>(tab[(int64_t)1 * T + cr.tensor]);
+  uint16_t* m = reinterpret_cast<uint16_t*>(tab[(int64_t)2 * T + cr.tensor]);
+  uint16_t* v = reinterpret_cast<uint16_t*>(tab[(int64_t)3 * T + cr.tensor]);
+  const int64_t n = tab[(int64_t)4 * T + cr.tensor];
+  const int64_t cols = tab[(int64_t)5 * T + cr.tensor];
+  const float gs = grad_scale ? *grad_scale : 1.0f;
+  const int tid = threadIdx.x;
+  if (cols == 0) {  // flat chunk (same arithmetic and traversal as adamw_multi_kernel)
+    const int64_t lo = (int64_t)cr.chunk * chunk_elems, hi = min(n, lo + chunk_elems);
+    const bool aligned = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
+    int64_t done = lo;
+    if (aligned) {
+      const int64_t v0 = lo >> 3, v1 = hi >> 3;
+      for (int64_t i = v0 + tid; i < v1; i += 256) {
+        v4i pv = reinterpret_cast<const v4i*>(p)[i];
+        const v4i gv = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(g) + i);
+        v4i mv = reinterpret_cast<const v4i*>(m)[i];
+        v4i vv = reinterpret_cast<const v4i*>(v)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float pl = __uint_as_float((u32)pv[j] << 16), ph = __uint_as_float((u32)pv[j] & 0xFFFF0000u);
+          const float gl = gs * __uint_as_float((u32)gv[j] << 16), gh = gs * __uint_as_float((u32)gv[j] & 0xFFFF0000u);
+          float ml = __uint_as_float((u32)mv[j] << 16), mh = __uint_as_float((u32)mv[j] & 0xFFFF0000u);
+          float vl = __uint_as_float((u32)vv[j] << 16), vh = __uint_as_float((u32)vv[j] & 0xFFFF0000u);
+          adam_one(pl, gl, ml, vl, a);
+          adam_one(ph, gh, mh, vh, a);
+          pv[j] = (int)pack_bf16x2(pl, ph);
+          mv[j] = (int)pack_bf16x2(ml, mh);
+          vv[j] = (int)pack_bf16x2(vl, vh);
+        }
+        reinterpret_cast<v4i*>(p)[i] = pv;
+        reinterpret_cast<v4i*>(m)[i] = mv;
+        reinterpret_cast<v4i*>(v)[i] = vv;
+      }
+      done = v1 << 3;
+    }
+    for (int64_t k = done + tid; k < hi; k += 256) {
+      float pf = bf16_bits_to_float(p[k]), mf = bf16_bits_to_float(m[k]), vf = bf16_bits_to_float(v[k]);
+      adam_one(pf, gs * bf16_bits_to_float(g[k]), mf, vf, a);
+      p[k] = (uint16_t)float_to_bf16_bits(pf);
+      m[k] = (uint16_t)float_to_bf16_bits(mf);
+      v[k] = (uint16_t)float_to_bf16_bits(vf);
+    }
+    return;
+  }
+  // tile of a weight with an FP8 sink
+  uint8_t* y = reinterpret_cast<uint8_t*>(tab[(int64_t)6 * T + cr.tensor]);
+  uint8_t* yT = reinterpret_cast<uint8_t*>(tab[(int64_t)7 * T + cr.tensor]);
+  const int64_t ld_y = tab[(int64_t)8 * T + cr.tensor], ld_yT = tab[(int64_t)9 * T + cr.tensor];
+  const float scale = *reinterpret_cast<const float*>(tab[(int64_t)10 * T + cr.tensor]);
+  float* amax_out = reinterpret_cast<float*>(tab[(int64_t)11 * T + cr.tensor]);
+  const int64_t rows = n / cols;
+  const int tiles_c = (int)((cols + 127) >> 7);
+  const int lane = tid & 63, wave = tid >> 6;
+  const int tile_r = cr.chunk / tiles_c, tile_c = cr.chunk % tiles_c;
+  const int64_t r0 = (int64_t)tile_r * 128 + (wave >> 1) * 64 + (lane >> 3) * 8;
+  const int64_t c0 = (int64_t)tile_c * 128 + (wave & 1) * 64 + (lane & 7) * 8;
+  float amax = 0.0f;
+  if (r0 < rows && c0 < cols) {
+    u32 lo[8], hi[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int64_t idx = ((r0 + i) * cols + c0) >> 3;
+      v4i pv = reinterpret_cast<const v4i*>(p)[idx];
+      const v4i gv = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(g) + idx);
+      v4i mv = reinterpret_cast<const v4i*>(m)[idx];
+      v4i vv = reinterpret_cast<const v4i*>(v)[idx];
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float pl = __uint_as_float((u32)pv[j] << 16), ph = __uint_as_float((u32)pv[j] & 0xFFFF0000u);
+        const float gl = gs * __uint_as_float((u32)gv[j] << 16), gh = gs * __uint_as_float((u32)gv[j] & 0xFFFF0000u);
+        float ml = __uint_as_float((u32)mv[j] << 16), mh = __uint_as_float((u32)mv[j] & 0xFFFF0000u);
+        float vl = __uint_as_float((u32)vv[j] << 16), vh = __uint_as_float((u32)vv[j] & 0xFFFF0000u);
+        adam_one(pl, gl, ml, vl, a);
+        adam_one(ph, gh, mh, vh, a);
+        const u32 pw = pack_bf16x2(pl, ph);
+        pv[j] = (int)pw;
+        mv[j] = (int)pack_bf16x2(ml, mh);
+        vv[j] = (int)pack_bf16x2(vl, vh);
+        f[2 * j] = __uint_as_float(pw << 16);          // the ROUNDED weight: what the next forward's cast would read
+        f[2 * j + 1] = __uint_as_float(pw & 0xFFFF0000u);
+      }
+      reinterpret_cast<v4i*>(p)[idx] = pv;
+      reinterpret_cast<v4i*>(m)[idx] = mv;
+      reinterpret_cast<v4i*>(v)[idx] = vv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, (f[j] != f[j]) ? 0.0f : fabsf(f[j]));
+      lo[i] = cvt4_fp8<MI_FMT_E4M3>(f[0] * scale, f[1] * scale, f[2] * scale, f[3] * scale);
+      hi[i] = cvt4_fp8<MI_FMT_E4M3>(f[4] * scale, f[5] * scale, f[6] * scale, f[7] * scale);
+    }
+    if (y != nullptr) {
+      uint8_t* dst = y + r0 * ld_y + c0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<uint2*>(dst + (int64_t)i * ld_y) = make_uint2(lo[i], hi[i]);
+    }
+    if (yT != nullptr) {
+      u32 ta[4], tb[4], tc[4], td[4];
+      transpose4x4(lo[0], lo[1], lo[2], lo[3], ta[0], ta[1], ta[2], ta[3]);
+      transpose4x4(lo[4], lo[5], lo[6], lo[7], tb[0], tb[1], tb[2], tb[3]);
+      transpose4x4(hi[0], hi[1], hi[2], hi[3], tc[0], tc[1], tc[2], tc[3]);
+      transpose4x4(hi[4], hi[5], hi[6], hi[7], td[0], td[1], td[2], td[3]);
+      uint8_t* dst = yT + c0 * ld_yT + r0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<uint2*>(dst + (int64_t)j * ld_yT) = make_uint2(ta[j], tb[j]);
+        *reinterpret_cast<uint2*>(dst + (int64_t)(j + 4) * ld_yT) = make_uint2(tc[j], td[j]);
+      }
+    }
+  }
+  if (amax_out != nullptr) {
+    amax = wave_max(amax);
+    if (lane == 0) s_amax[wave] = amax;
+    __syncthreads();
+    if (tid == 0) {
+      const float mx = fmaxf(fmaxf(s_amax[0], s_amax[1]), fmaxf(s_amax[2], s_amax[3]));
+      if (mx > 0.0f && mx > __builtin_nontemporal_load(amax_out)) atomicMax(reinterpret_cast<unsigned int*>(amax_out), __float_as_uint(mx));
+    }
+  }
+}
+
 // Embedding weight gradient added IN PLACE into an existing [V, H] bf16 gradient (the tied lm_head / embedding table already
 // holds the lm_head wgrad): grad[id, :] += alpha * sum over the tokens with that id of dY[token, :].  Replaces
 // aten::embedding_dense_backward (zero-fill of a dense [V, H] + scatter) followed by a dense add -- 2 x 788 MB written and
@@ -280,6 +414,17 @@ extern "C" int mi_adamw_bf16_multi(const int64_t* table, int n_tensors, const in
   hipLaunchKernelGGL(mi::adamw_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, table, n_tensors,
                      (const mi::ChunkRef*)chunks, chunk_elems, grad_scale, make_adam_args(lr, beta1, beta2, eps, weight_decay, step));
   MI_CHECK_LAUNCH("mi_adamw_bf16_multi launch");
+  return MI_OK;
+}
+
+extern "C" int mi_adamw_cast_bf16_multi(const int64_t* table, int n_tensors, const int32_t* chunks, int n_chunks, int chunk_elems,
+                                        const float* grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                        int64_t step, void* stream) {
+  MI_CHECK_ARG(table && chunks, "mi_adamw_cast_bf16_multi: null pointer");
+  MI_CHECK_ARG(n_tensors >= 1 && n_chunks >= 1 && chunk_elems >= 8 && chunk_elems % 8 == 0 && step >= 1, "mi_adamw_cast_bf16_multi: bad sizes");
+  hipLaunchKernelGGL(mi::adamw_cast_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, table, n_tensors,
+                     (const mi::ChunkRef*)chunks, chunk_elems, grad_scale, make_adam_args(lr, beta1, beta2, eps, weight_decay, step));
+  MI_CHECK_LAUNCH("mi_adamw_cast_bf16_multi launch");
   return MI_OK;
 }
 

@@ -32,33 +32,70 @@ class ClippedAdamW(torch.optim.Optimizer):
 
     CHUNK = 65536  # elements per workgroup of the multi-tensor kernels (128 KiB of bf16)
 
+    TILE = 128  # a sink tensor's chunks are TILE x TILE tiles of the weight matrix (mi_adamw_cast_bf16_multi)
+
+    @staticmethod
+    def _sink_of(p):
+        """(sink, row offset, rows) when the FP8 copies of this weight are kept current by the optimiser (module.WeightSink)."""
+        s = getattr(p, "_mi_fp8_sink", None)
+        if s is None or not p.is_contiguous() or p.dim() != 2:
+            return None
+        sink, r0, n = s
+        if n != p.shape[0] or sink.w8.shape[1] != p.shape[1] or p.shape[0] % 8 or p.shape[1] % 8:
+            return None
+        return s
+
     def _plan(self, group_items, dev):
-        """Device tables of one parameter group for the multi-tensor kernels.  The chunk list only depends on the tensor sizes
-        and is built once; the address table is re-uploaded when an address changed (gradients are new tensors every step,
-        though the caching allocator usually hands back the same blocks)."""
+        """Device tables of one parameter group for the multi-tensor kernels.  The chunk lists only depend on the tensor sizes
+        (and on which tensors have an FP8 sink) and are built once; the address table is re-uploaded when an address changed
+        (gradients are new tensors every step, though the caching allocator usually hands back the same blocks)."""
         # one plan per PARTITION (the parameters of a group that share a step count), not per group: two partitions of one
         # group must not share address table / partial sums
         key = (id(group_items[0][0]), tuple(id(p) for _, p in group_items))
         sizes = tuple(p.numel() for _, p in group_items)
+        sinks = tuple(self._sink_of(p) for _, p in group_items)
+        sink_sig = tuple(None if s is None else (id(s[0]), s[1]) for s in sinks)
         plan = self._plans.get(key)
-        if plan is None or plan["sizes"] != sizes:
-            refs = []
-            for t, n in enumerate(sizes):
-                refs.extend((t, c) for c in range((n + self.CHUNK - 1) // self.CHUNK))
+        if plan is None or plan["sizes"] != sizes or plan["sink_sig"] != sink_sig:
+            refs, refs_cast = [], []
+            for t, (n, (_, p), s) in enumerate(zip(sizes, group_items, sinks)):
+                flat = [(t, c) for c in range((n + self.CHUNK - 1) // self.CHUNK)]
+                refs.extend(flat)
+                if s is None:
+                    refs_cast.extend(flat)
+                else:
+                    tr, tc = (p.shape[0] + self.TILE - 1) // self.TILE, (p.shape[1] + self.TILE - 1) // self.TILE
+                    refs_cast.extend((t, c) for c in range(tr * tc))
             chunks = torch.tensor(refs, dtype=torch.int32).to(dev)
-            plan = {"sizes": sizes, "chunks": chunks, "n_chunks": len(refs), "addr": None,
-                    "table": torch.empty((5, len(sizes)), dtype=torch.int64, device=dev),
-                    "host": [torch.empty((5, len(sizes)), dtype=torch.int64).pin_memory() for _ in range(2)], "flip": 0,
+            any_sink = any(s is not None for s in sinks)
+            plan = {"sizes": sizes, "sink_sig": sink_sig, "chunks": chunks, "n_chunks": len(refs), "addr": None,
+                    "chunks_cast": torch.tensor(refs_cast, dtype=torch.int32).to(dev) if any_sink else None, "n_chunks_cast": len(refs_cast),
+                    "table": torch.empty((12, len(sizes)), dtype=torch.int64, device=dev),
+                    "host": [torch.empty((12, len(sizes)), dtype=torch.int64).pin_memory() for _ in range(2)], "flip": 0,
                     "uploaded": [None, None],
                     "partials": torch.empty(len(refs), dtype=torch.float32, device=dev)}
             self._plans[key] = plan
-        rows = [[], [], [], [], list(sizes)]
-        for _, p in group_items:
+        rows = [[], [], [], [], list(sizes), [], [], [], [], [], [], []]
+        for (_, p), s in zip(group_items, sinks):
             st = self.state[p]
             rows[0].append(p.data_ptr())
             rows[1].append(p.grad.data_ptr())
             rows[2].append(st["exp_avg"].data_ptr())
             rows[3].append(st["exp_avg_sq"].data_ptr())
+            if s is None:
+                for r in range(5, 12):
+                    rows[r].append(0)
+            else:
+                sink, r0, _ = s
+                K, N = p.shape[1], sink.w8.shape[0]
+                rows[5].append(K)
+                rows[6].append(sink.w8.data_ptr() + r0 * K)
+                rows[7].append(sink.w8t.data_ptr() + r0)
+                rows[8].append(K)
+                rows[9].append(N)
+                rows[10].append(sink.scale.data_ptr())
+                rows[11].append(sink.amax.data_ptr())
+        plan["sinks"] = sinks
         if plan["addr"] != rows:
             # two pinned staging buffers, each guarded by an event recorded behind its last upload: the host may run several
             # steps ahead of the device, and rewriting a buffer whose async H2D copy has not run yet would hand the kernels
@@ -112,15 +149,31 @@ class ClippedAdamW(torch.optim.Optimizer):
             self.last_grad_norm = total
             coef = (self.max_grad_norm / (total + 1e-6)).clamp(max=1.0).reshape(1)  # clip_grad_norm_'s coefficient
             coef_ptr = coef.data_ptr()
+        touched, sinks_seen = set(), {}
         for gi, plan in plans:
             group = gi[0][0]
             for _, p in gi:
                 self.state[p]["step"] += 1
             b1, b2 = group["betas"]
-            rc = lib.mi_adamw_bf16_multi(plan["table"].data_ptr(), len(gi), plan["chunks"].data_ptr(), plan["n_chunks"], self.CHUNK,
-                                         coef_ptr, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
-                                         int(self.state[gi[0][1]]["step"]), st)
-            _lib.check(rc, "mi_adamw_bf16_multi")
+            if plan["chunks_cast"] is not None:  # some weights of this partition have FP8 sinks: update + cast in one pass
+                rc = lib.mi_adamw_cast_bf16_multi(plan["table"].data_ptr(), len(gi), plan["chunks_cast"].data_ptr(), plan["n_chunks_cast"],
+                                                  self.CHUNK, coef_ptr, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
+                                                  int(self.state[gi[0][1]]["step"]), st)
+                _lib.check(rc, "mi_adamw_cast_bf16_multi")
+            else:
+                rc = lib.mi_adamw_bf16_multi(plan["table"].data_ptr(), len(gi), plan["chunks"].data_ptr(), plan["n_chunks"], self.CHUNK,
+                                             coef_ptr, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
+                                             int(self.state[gi[0][1]]["step"]), st)
+                _lib.check(rc, "mi_adamw_bf16_multi")
             # the kernels write through raw addresses: tell autograd (and every cache keyed on `_version`, wcast.py)
             torch.autograd.graph.increment_version([p for _, p in gi])
+            touched.update(id(p) for _, p in gi)
+            for s in plan["sinks"]:
+                if s is not None:
+                    sinks_seen[id(s[0])] = s[0]
+        for sink in sinks_seen.values():  # copies are current only if EVERY part of the operand was rewritten in this step
+            if all(id(w) in touched for w, _, _ in sink.parts):
+                sink.mark()
+            else:
+                sink.stamp = None
         return None

@@ -60,6 +60,7 @@ class MetaArena:
         self.fp8_max = torch.full((self.CAP,), fmt.value.max_fwd if forward else fmt.value.max_bwd,
                                   dtype=torch.float32, device=device)
         self.used = 0
+        self.generation = 0  # bumped whenever scales may change (update, load_state): FP8 copies made before are stale
         self.reduce_amax = True
         self.group = None
         self._snap: Optional[torch.Tensor] = None  # copy of scale_inv taken at most once between two updates
@@ -93,6 +94,7 @@ class MetaArena:
             return
         n = self.used
         self._snap = None
+        self.generation += 1
         self.reduce()
         ops.scale_update(self.hist[:, :n], self.scale[:n], self.scale_inv[:n], self.fp8_max[:n], self.margin, self.algo)
 
@@ -124,6 +126,7 @@ class ModuleMeta:
     def load_state(self, st: Dict[str, torch.Tensor]) -> None:
         a, s, n = self.arena, self.start, self.n
         a._snap = None
+        a.generation += 1
         a.scale[s:s + n].copy_(st["scale"])
         a.scale_inv[s:s + n].copy_(st["scale_inv"])
         h = st["amax_history"]

@@ -15,6 +15,7 @@ FP8 is enabled.  Outside `fp8_autocast` (or with enabled=False) the modules are 
 from __future__ import annotations
 
 import io
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -108,6 +109,38 @@ class _GemmSpec:
         self.training = training
 
 
+class WeightSink:
+    """FP8 copies (w8 [N,K], w8T [K,N]) of one GEMM's weight operand that the OPTIMISER keeps current (optim.ClippedAdamW ->
+    mi_adamw_cast_bf16_multi): under delayed scaling the scale of the next forward's weight cast is final once this step's
+    forward has ended, and the optimiser streams every weight anyway, so it emits the bytes (and the amax) that forward
+    would have produced -- bitwise -- and the forward skips its weight casts (141 launches and one read of all weights per
+    step on Llama-3.2-3B).  `stamp` = (versions of the parts, generation of the scale arena) at emission; the copies are used
+    only while both still match (no other write to the weights, no scale update in between: an evaluation pass or a second
+    micro-batch re-casts as before)."""
+    __slots__ = ("w8", "w8t", "parts", "arena", "scale", "amax", "stamp")
+
+    def __init__(self, weights, ns, N, K, dev, mf, slot):
+        self.w8 = torch.empty((N, K), dtype=torch.uint8, device=dev)
+        self.w8t = torch.empty((K, N), dtype=torch.uint8, device=dev)
+        self.parts, r = [], 0
+        for w, n in zip(weights, ns):
+            self.parts.append((w, r, n))
+            w._mi_fp8_sink = (self, r, n)
+            r += n
+        self.arena, self.scale, self.amax = mf.arena, mf.scale(slot), mf.amax(slot)
+        self.stamp = None
+
+    def fresh(self) -> bool:
+        return self.stamp is not None and self.stamp == (tuple(w._version for w, _, _ in self.parts), self.arena.generation)
+
+    def mark(self) -> None:  # called by the optimiser after it rewrote every part in this step
+        self.stamp = (tuple(w._version for w, _, _ in self.parts), self.arena.generation)
+
+
+def weight_sinks_enabled() -> bool:
+    return os.environ.get("LLM_FP8_AMD_NO_OPT_WCAST") != "1"
+
+
 def _cast_weights(spec: _GemmSpec, g: int, weights, ns, N: int, K: int, dev, need_t: bool):
     """FP8 copies (w8 [N,K], w8T [K,N]) of the concatenated weight parts of GEMM `g` under delayed scaling, plus the
     scale_inv they were quantised with.  Honours the micro-batch cache of the spec (see _GemmSpec)."""
@@ -117,6 +150,21 @@ def _cast_weights(spec: _GemmSpec, g: int, weights, ns, N: int, K: int, dev, nee
         hit = spec.wcache.get(ck)
         if hit is not None and (hit[1] is not None or not need_t):
             return hit
+    # (no grad-mode test here: inside an autograd Function's forward grad mode is always off; fresh copies are the bytes a
+    # cast would produce now in any mode)
+    if spec.wcache is not None and spec.training and spec.fmt_fwd == 0 and weight_sinks_enabled():
+        sink = spec.wcache.get(("sink", g))
+        if sink is None or sink.arena is not mf.arena or len(sink.parts) != len(weights) or any(a is not b for (a, _, _), b in zip(sink.parts, weights)):
+            if all(w.dtype == torch.bfloat16 and w.is_contiguous() and w.dim() == 2 and w.shape[1] == K and isinstance(w, torch.nn.Parameter)
+                   for w in weights) and N % 8 == 0 and K % 8 == 0:
+                sink = spec.wcache[("sink", g)] = WeightSink(weights, ns, N, K, dev, mf, 3 * g + 1)
+            else:
+                sink = None
+        if sink is not None and sink.fresh():
+            siw = mf.scale_inv_snapshot()[3 * g + 1:3 * g + 2]
+            if spec.first_mb is True:
+                spec.wcache[ck] = (sink.w8, sink.w8t, siw)
+            return sink.w8, sink.w8t, siw
     keep = spec.first_mb is True and spec.wcache is not None
     want_t = need_t or keep
     w8 = torch.empty((N, K), dtype=torch.uint8, device=dev)

@@ -573,6 +573,69 @@ def test_grad_output_handoffs_are_bitwise_the_unfused_path(te, dev, scenario, mo
     assert torch.equal(h1, h0) and torch.equal(w1, w0)
 
 
+@pytest.mark.parametrize("scenario,accum", [("default", 1), ("hybrid", 1), ("default", 2)])
+def test_optimizer_weight_cast_handoff_is_bitwise_the_forward_cast(te, dev, scenario, accum, monkeypatch):
+    """module.WeightSink + mi_adamw_cast_bf16_multi: the optimiser emits the FP8 weights (and their amax) of the next forward;
+    against the ordinary route (every forward casts its weights): same losses, weights, Adam moments and amax histories after 4
+    optimiser steps, bit for bit -- and the forward really stops casting weights.  accum = 2: the second micro-batch of a
+    window sees a NEWER scale than the optimiser used, so it must fall back to casting."""
+    from llm_fp8_amd import train
+    from llm_fp8_amd.pytorch.fp8 import FP8GlobalStateManager as G
+    from llm_fp8_amd.pytorch import ops as _ops
+
+    def run(disable):
+        G.reset()
+        if disable:
+            monkeypatch.setenv("LLM_FP8_AMD_NO_OPT_WCAST", "1")
+        else:
+            monkeypatch.delenv("LLM_FP8_AMD_NO_OPT_WCAST", raising=False)
+        calls = {"n": 0}
+        orig = _ops.cast_amax
+
+        def counting(x, *a, **k):
+            if isinstance(x, torch.nn.Parameter) or getattr(x, "_is_param", False) or x.requires_grad and x.is_leaf:
+                calls["n"] += 1
+            return orig(x, *a, **k)
+
+        monkeypatch.setattr(_ops, "cast_amax", counting)
+        cfg = train.TrainingConfig(model_name="llama-3.2-3b", batch_size=2, max_seq_length=128, mixed_precision="fp8",
+                                   fp8_scenario=scenario, use_te=True, sharding_mode="none", num_hidden_layers=2, vocab_size=2048,
+                                   learning_rate=1e-3, num_warmup_steps=0)
+        torch.manual_seed(23)
+        device = torch.device(dev)
+        model = train.prepare_model(train.create_model(cfg, device), cfg)
+        opt, sched = train.create_optimizer(model, cfg)
+        model.train()
+        gen = torch.Generator(device=device).manual_seed(9)
+        losses = []
+        for _ in range(4):
+            mbs = [train.synthetic_batch(cfg, 2048, device, gen) for _ in range(accum)]
+            losses.append(train.train_step(model, mbs if accum > 1 else mbs[0], opt, sched, cfg).item())
+        # an evaluation pass in between must not disturb anything (it quantises with the current scales and casts for itself)
+        model.eval()
+        with torch.no_grad():
+            ev = model(**train.synthetic_batch(cfg, 2048, device, gen)).loss.item()
+        model.train()
+        losses.append(train.train_step(model, train.synthetic_batch(cfg, 2048, device, gen), opt, sched, cfg).item())
+        # the optimiser deposits amax(w) into history row 0 right away, the ordinary route at the next forward's weight cast:
+        # compare the state at a common point -- after one more training-mode forward (its exit rolls the histories)
+        losses.append(model(**train.synthetic_batch(cfg, 2048, device, gen)).loss.item())
+        hist = torch.cat([torch.cat([a.hist[:, :a.used].reshape(-1), a.scale[:a.used]]) for a in G._arenas.values()]).clone()
+        flat = torch.cat([p.detach().reshape(-1).view(torch.int16) for p in model.parameters()]).clone()
+        mom = torch.cat([opt.state[p]["exp_avg_sq"].reshape(-1).view(torch.int16) for p in model.parameters() if p in opt.state]).clone()
+        monkeypatch.setattr(_ops, "cast_amax", orig)
+        return losses, ev, hist, flat, mom, calls["n"]
+
+    try:
+        l1, e1, h1, w1, m1, n1 = run(False)
+        l0, e0, h0, w0, m0, n0 = run(True)
+    finally:
+        G.reset()
+    assert l1 == l0 and e1 == e0, (l1, l0)
+    assert torch.equal(h1, h0) and torch.equal(w1, w0) and torch.equal(m1, m0)
+    assert n1 < n0, (n1, n0)   # weight casts really disappeared from the forwards that follow an optimiser step
+
+
 def test_dy_handoff_steps_aside_when_the_gradient_is_observed(te, dev):
     """module.handoff_readers: `retain_grad()` / a tensor hook on the logits, or anomaly mode, must see the REAL d(logits), not
     the unwritten placeholder of the cross-entropy -> lm_head hand-off; and the step must equal the no-hand-off step bit for bit."""
