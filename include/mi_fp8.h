@@ -53,8 +53,7 @@ extern "C" {
  * mi_abi_version() returns the value the library was built with; a binding compares it with the header it was written
  * against (llm_fp8_amd/_lib.py does at load time).
  *   1  round 1 (the surface of SURVEY.md 8b + fused neighbours)
- *   2  round 2: mi_gemm_fp8 / mi_gemm_mxfp8 algo values 20-24, 46 (diagnostic builds), mi_adamw_cast_bf16_multi,
- *      mi_gemm_fp8_grouped
+ *   2  round 2: mi_gemm_fp8 algo values 20-24, 46 (diagnostic builds), mi_adamw_cast_bf16_multi, mi_transpose_u8
  */
 #define MI_ABI_VERSION 2
 int mi_abi_version(void);
@@ -73,6 +72,9 @@ int mi_device_supported(void);
  */
 int mi_cast_amax(const void* x_bf16, void* y_fp8, void* yT_fp8, const float* scale, float* amax,
                  int64_t rows, int64_t cols, int64_t ld_y, int64_t ld_yT, int fmt, void* stream);
+/* yT[c * ld_yT + r] = y[r * ld_y + c] on FP8 bytes (rows, cols multiples of 8): the transposed copy of an operand that was
+ * quantised elsewhere -- after an FP8 all-gather of row shards (llm_fp8_amd.distributed.ShardedFP8DP). */
+int mi_transpose_u8(const void* y, void* yT, int64_t rows, int64_t cols, int64_t ld_y, int64_t ld_yT, void* stream);
 /*
  * mi_cast_amax that also returns the column sums of x (the bias gradient when x = grad_output of a Linear,
  * `db = sum_M dy`): colsum_partial [ceil(rows/64), cols] fp32, one row per 64-row tile, to be reduced by

@@ -22,6 +22,7 @@ SIGNATURES = {
     "mi_last_error": [],
     "mi_device_supported": [],
     "mi_cast_amax": [_p, _p, _p, _p, _p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _p],
+    "mi_transpose_u8": [_p, _p, _c_i64, _c_i64, _c_i64, _c_i64, _p],
     "mi_scale_update": [_p, _p, _p, _p, _c_int, _c_int, _c_i64, _c_int, _c_int, _p],
     "mi_gemm_fp8": [_p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64,
                     _c_int, _c_int, _c_int, _c_int, _p],

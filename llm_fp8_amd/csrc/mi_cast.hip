@@ -253,6 +253,52 @@ static int cast_amax_impl(const void* x_bf16, void* y_fp8, void* yT_fp8, const f
   return mi::launch_cast<MI_FMT_E5M2>(x_bf16, y_fp8, yT_fp8, scale, amax, rows, cols, ld_y, ld_yT, st, colsum);
 }
 
+namespace mi {
+// yT[c * ld_yT + r] = y[r * ld_y + c] for FP8 bytes: the transposed copy of an already quantised operand (after an FP8
+// all-gather of row shards the wgrad / dgrad GEMMs still want the [K, N] copy: distributed.ShardedFP8DP).  Tiling of the cast
+// kernels: 128 x 128 bytes per workgroup, an 8 x 8 block per lane, byte transpose in registers (v_perm_b32).
+__global__ __launch_bounds__(256) void transpose_u8_kernel(const uint8_t* __restrict__ y, uint8_t* __restrict__ yT, int64_t rows,
+                                                           int64_t cols, int64_t ld_y, int64_t ld_yT, int tiles_c) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile_r = blockIdx.x / tiles_c, tile_c = blockIdx.x % tiles_c;
+  const int64_t r0 = (int64_t)tile_r * 128 + (wave >> 1) * 64 + (lane >> 3) * 8;
+  const int64_t c0 = (int64_t)tile_c * 128 + (wave & 1) * 64 + (lane & 7) * 8;
+  if (r0 >= rows || c0 >= cols) return;
+  u32 lo[8], hi[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint2 v = *reinterpret_cast<const uint2*>(y + (r0 + i) * ld_y + c0);
+    lo[i] = v.x;
+    hi[i] = v.y;
+  }
+  u32 a[4], b[4], c[4], d[4];
+  transpose4x4(lo[0], lo[1], lo[2], lo[3], a[0], a[1], a[2], a[3]);
+  transpose4x4(lo[4], lo[5], lo[6], lo[7], b[0], b[1], b[2], b[3]);
+  transpose4x4(hi[0], hi[1], hi[2], hi[3], c[0], c[1], c[2], c[3]);
+  transpose4x4(hi[4], hi[5], hi[6], hi[7], d[0], d[1], d[2], d[3]);
+  uint8_t* dst = yT + c0 * ld_yT + r0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    *reinterpret_cast<uint2*>(dst + (int64_t)j * ld_yT) = make_uint2(a[j], b[j]);
+    *reinterpret_cast<uint2*>(dst + (int64_t)(j + 4) * ld_yT) = make_uint2(c[j], d[j]);
+  }
+}
+}  // namespace mi
+
+extern "C" int mi_transpose_u8(const void* y, void* yT, int64_t rows, int64_t cols, int64_t ld_y, int64_t ld_yT, void* stream) {
+  MI_CHECK_ARG(y && yT, "mi_transpose_u8: null pointer");
+  MI_CHECK_ARG(rows >= 0 && cols >= 0 && rows % 8 == 0 && cols % 8 == 0 && ld_y >= cols && ld_yT >= rows && ld_y % 8 == 0 && ld_yT % 8 == 0,
+               "mi_transpose_u8: rows, cols and leading dimensions must be multiples of 8 (got %lld x %lld)", (long long)rows, (long long)cols);
+  MI_CHECK_ARG(((uintptr_t)y % 8) == 0 && ((uintptr_t)yT % 8) == 0, "mi_transpose_u8: pointers must be 8-byte aligned");
+  if (rows == 0 || cols == 0) return MI_OK;
+  const int64_t tiles_r = (rows + 127) / 128, tiles_c = (cols + 127) / 128;
+  MI_CHECK_ARG(tiles_r * tiles_c < (1LL << 31), "mi_transpose_u8: too many tiles");
+  hipLaunchKernelGGL(mi::transpose_u8_kernel, dim3((unsigned)(tiles_r * tiles_c)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)y,
+                     (uint8_t*)yT, rows, cols, ld_y, ld_yT, (int)tiles_c);
+  MI_CHECK_LAUNCH("mi_transpose_u8 launch");
+  return MI_OK;
+}
+
 extern "C" int mi_cast_amax(const void* x_bf16, void* y_fp8, void* yT_fp8, const float* scale, float* amax,
                             int64_t rows, int64_t cols, int64_t ld_y, int64_t ld_yT, int fmt, void* stream) {
   return cast_amax_impl(x_bf16, y_fp8, yT_fp8, scale, amax, rows, cols, ld_y, ld_yT, fmt, stream, nullptr);

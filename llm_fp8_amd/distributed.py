@@ -36,10 +36,11 @@ _ALIGN = 64  # elements: slots start on 128-byte boundaries (bf16); sizes that a
 
 
 class _Bucket:
-    __slots__ = ("arena", "start", "end", "params", "pending")
+    __slots__ = ("arena", "start", "end", "params", "pending", "shard_of")
 
     def __init__(self, arena: int, start: int):
         self.arena, self.start, self.end, self.params, self.pending = arena, start, start, [], 0
+        self.shard_of = None  # ShardedFP8DP: the one row-sharded weight of this bucket (reduce-scatter instead of all-reduce)
 
 
 def _param_groups_in_backward_order(module: torch.nn.Module) -> List[List[torch.nn.Parameter]]:
@@ -89,6 +90,7 @@ class GradArenaDP(torch.nn.Module):
         self.arenas: List[torch.Tensor] = []
         self.buckets: List[_Bucket] = []
         self._bucket_of: Dict[int, _Bucket] = {}
+        self._prepare_sharding()
         self._build(_param_groups_in_backward_order(module), int(bucket_mb * (1 << 20)))
         if broadcast and self.world > 1:
             self._broadcast_state()
@@ -98,6 +100,12 @@ class GradArenaDP(torch.nn.Module):
             self._install_sparse_embeddings()
 
     # ------------------------------------------------------------------------------------------------ construction
+    def _prepare_sharding(self):
+        """Hook for ShardedFP8DP (decides which weights get a bucket of their own and a reduce-scatter)."""
+
+    def _own_bucket(self, p) -> bool:
+        return False
+
     def _build(self, groups, bucket_bytes: int):
         keys: Dict[tuple, int] = {}
         sizes: List[int] = []
@@ -117,7 +125,8 @@ class GradArenaDP(torch.nn.Module):
             p._mi_grad_buf = arena[off:off + p.numel()].view(p.shape)
             p._mi_grad_slot = (arena, off)
             b = open_bucket.get(a)
-            if b is not None and p.numel() * arena.element_size() >= bucket_bytes:
+            own = self._own_bucket(p)
+            if b is not None and (own or p.numel() * arena.element_size() >= bucket_bytes):
                 # a parameter that fills a bucket by itself (the embedding table, whose gradient is complete only at the very
                 # end of backward) does not hold back the reduction of what came before it
                 del open_bucket[a]
@@ -131,7 +140,9 @@ class GradArenaDP(torch.nn.Module):
             # the buckets that close last (the first layers: the tail of backward) are a quarter of the size, so that the
             # all-reduce still in flight when backward ends is short
             cap = bucket_bytes if off < 0.85 * sizes[a] else max(bucket_bytes // 4, 1)
-            if (b.end - b.start) * arena.element_size() >= cap:
+            if own:
+                b.shard_of = p
+            if own or (b.end - b.start) * arena.element_size() >= cap:
                 del open_bucket[a]
             p.register_post_accumulate_grad_hook(self._on_grad)
         for b in self.buckets:
@@ -283,6 +294,147 @@ class GradArenaDP(torch.nn.Module):
         return {"arenas": [{"dtype": str(a.dtype), "bytes": a.numel() * a.element_size()} for a in self.arenas],
                 "buckets": [(b.end - b.start) * self.arenas[b.arena].element_size() for b in self.buckets],
                 "world": self.world}
+
+
+class ShardedFP8DP(GradArenaDP):
+    """The FSDP-full-shard counterpart with an FP8 all-gather (`--sharding_mode fsdp_fp8`).
+
+    torch's FSDP, as the reference wraps it (train_multi_gpu.py:414-445), all-gathers every layer's bf16 flat parameter in the
+    forward AND again in the backward and reduce-scatters bf16 gradients: 6 bytes per parameter and step over xGMI, plus a cast
+    of every weight after every gather.  The FP8 Linear needs none of the bf16 weights in its backward -- it saved w8T -- so:
+
+      * every GEMM weight is ROW-sharded over the ranks (a [N, K] row-major weight cut into `world` equal row blocks = equal
+        contiguous flat chunks).  A rank keeps the AdamW moments of its rows only and updates those rows only;
+      * backward: the wgrad of a sharded weight is reduce-scattered (AVG) as soon as it is complete -- 2 bytes per parameter;
+        every other parameter (norms, biases, embedding tables) is small or needed in bf16 everywhere and goes through the
+        bucketed all-reduce of the base class;
+      * optimiser: ClippedAdamW on the shards; mi_adamw_cast_bf16_multi quantises the updated rows on the fly (delayed scaling:
+        the scale of the next forward is already final) into the rank's rows of the operand's FP8 copy (module.WeightSink);
+      * after the step ONE all-gather per operand moves the FP8 rows -- 1 byte per parameter -- and a local byte transpose
+        (mi_transpose_u8) rebuilds w8T.  Forward and backward of the next step run entirely on these copies: no gather in the
+        backward, no cast after a gather.  3 bytes per parameter and step instead of 6.
+
+    amax: a rank deposits the amax of ITS rows; the arenas' MAX all-reduce (fp8.MetaArena.reduce) makes it global before the
+    next scale update, exactly as for activations.  The bf16 master tensors stay allocated at full size (rows of other ranks go
+    stale; `gather_master_weights()` refreshes them for evaluation without FP8 or for a checkpoint).  MXFP8 has no sink (its
+    quantiser is a different kernel): such modules stay replicated.  Unmeasured on multi-GPU hardware (the driver alone runs
+    N > 1); rehearsed with 2 ranks sharing one GPU (tests/test_distributed_gpu.py) and at world size 1 over RCCL."""
+
+    def _prepare_sharding(self):
+        from .pytorch.module import Linear, LayerNormLinear, LayerNormMLP
+        rank = dist.get_rank(self.group)
+        self.rank = rank
+        tables = {id(m.weight) for m in self.module.modules() if isinstance(m, torch.nn.Embedding)}
+        self._sharded: Dict[int, torch.nn.Parameter] = {}
+        for m in self.module.modules():
+            if isinstance(m, (Linear, LayerNormLinear, LayerNormMLP)):
+                for p in m._parameters.values():
+                    if (p is not None and p.requires_grad and p.dim() == 2 and id(p) not in tables and p.dtype == torch.bfloat16
+                            and p.is_contiguous() and p.shape[0] % (8 * self.world) == 0 and p.shape[1] % 8 == 0):
+                        self._sharded[id(p)] = p
+        self._shards: Dict[int, torch.nn.Parameter] = {}
+        for p in self._sharded.values():
+            n = p.shape[0] // self.world
+            r0 = rank * n
+            sp = torch.nn.Parameter(p.data[r0:r0 + n], requires_grad=True)  # aliases the rank's rows of the master weight
+            sp._mi_shard_grad = torch.zeros_like(sp)  # the reduce-scatter's output; becomes `.grad` when it has landed
+            sp._mi_shard_of = (p, r0, n)
+            self._shards[id(p)] = sp
+
+    def _own_bucket(self, p) -> bool:
+        return id(p) in self._sharded
+
+    def _launch(self, b: _Bucket):
+        p = b.shard_of
+        if p is None:
+            return super()._launch(b)
+        sp = self._shards[id(p)]
+        full, out = p._mi_grad_buf, sp._mi_shard_grad
+        if self.world == 1 and not _FORCE_COLLECTIVES:
+            out.copy_(full)
+            self._works.append((None, (p, sp, None), False))
+            return
+        if self._avg_in_collective:  # RCCL: reduce-scatter with the average taken in the collective
+            w = dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            self._works.append((w, (p, sp, None), False))
+            return
+        # gloo rehearsal (no reduce-scatter on this backend): all-reduce, scale, keep the rank's rows
+        w = dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._works.append((w, (p, sp, full), True))
+
+    def _finalize(self):
+        # sharded buckets carry (master, shard, full-gradient-or-None) instead of a flat arena slice: settle them here, the
+        # base class then handles the all-reduced buckets and the row-sparse embedding part
+        rest = []
+        for w, flat, summed in self._works:
+            if isinstance(flat, tuple):
+                p, sp, full = flat
+                if w is not None:
+                    w.wait()
+                if full is not None:
+                    _, r0, n = sp._mi_shard_of
+                    sp._mi_shard_grad.copy_(full[r0:r0 + n]).mul_(1.0 / self.world)
+                sp.grad = sp._mi_shard_grad
+                p.grad = None  # the full-size gradient has served: the next pass starts from an empty slot
+            else:
+                rest.append((w, flat, summed))
+        self._works[:] = rest
+        super()._finalize()
+
+    # ------------------------------------------------------------------------------------------------ optimiser side
+    def optimizer_param_groups(self):
+        """Two groups for optim.ClippedAdamW: replicated parameters (every rank updates them identically) and the row shards
+        (`sharded=True`: their squared gradient norm is summed over the ranks before the clip coefficient is formed)."""
+        rep = [p for p in self.module.parameters() if p.requires_grad and id(p) not in self._sharded]
+        seen, rep_u = set(), []
+        for p in rep:
+            if id(p) not in seen:
+                seen.add(id(p))
+                rep_u.append(p)
+        return [{"params": rep_u}, {"params": list(self._shards.values()), "sharded": True}]
+
+    def after_optimizer_step(self):
+        """All-gather the freshly quantised FP8 rows of every sharded operand (1 byte per parameter), rebuild the transposed
+        copies locally, and declare the copies current."""
+        from .pytorch import ops
+        sinks = {}
+        for p in self._sharded.values():
+            s = getattr(p, "_mi_fp8_sink", None)
+            if s is not None:
+                sinks[id(s[0])] = s[0]
+            elif self.world > 1:
+                # no FP8 sink (MXFP8 recipe, FP8 off): the module will read the bf16 master itself -> gather its rows (2 B/param)
+                n = p.shape[0] // self.world
+                mine = p.data[self.rank * n:(self.rank + 1) * n].clone()
+                dist.all_gather_into_tensor(p.data.view(-1), mine.view(-1), group=self.group)
+        for sink in sinks.values():
+            if not all(id(w) in self._sharded for w, _, _ in sink.parts):
+                sink.stamp = None  # an operand with a replicated part was updated in full by every rank's optimiser already
+                continue
+            for w, row_off, n in sink.parts:
+                rows = n // self.world
+                dst = sink.w8[row_off:row_off + n]
+                if self.world > 1 or _FORCE_COLLECTIVES:
+                    mine = dst[self.rank * rows:(self.rank + 1) * rows].clone()
+                    dist.all_gather_into_tensor(dst.view(-1), mine.view(-1), group=self.group)
+            ops.transpose_u8(sink.w8, out=sink.w8t)
+            sink.mark()
+
+    def gather_master_weights(self):
+        """Refresh the full bf16 master tensors from the ranks' shards (evaluation with FP8 off, checkpoints)."""
+        if self.world == 1:
+            return
+        with torch.no_grad():
+            for p in self._sharded.values():
+                n = p.shape[0] // self.world
+                mine = p.data[self.rank * n:(self.rank + 1) * n].clone()
+                dist.all_gather_into_tensor(p.data.view(-1), mine.view(-1), group=self.group)
+
+    def describe(self) -> dict:
+        d = super().describe()
+        d["sharded_weights"] = len(self._sharded)
+        d["sharded_bytes"] = sum(p.numel() * p.element_size() for p in self._sharded.values())
+        return d
 
 
 # debug / rehearsal: run the collectives even at world size 1 (exercises the RCCL stream hand-over on a one-GPU box)

@@ -38,6 +38,11 @@ class ClippedAdamW(torch.optim.Optimizer):
     def _sink_of(p):
         """(sink, row offset, rows) when the FP8 copies of this weight are kept current by the optimiser (module.WeightSink)."""
         s = getattr(p, "_mi_fp8_sink", None)
+        sh = getattr(p, "_mi_shard_of", None)
+        if sh is not None:  # a row shard of a master weight (distributed.ShardedFP8DP): rows [r0, r0 + n) of the full operand part
+            full, sr0, sn = sh
+            fs = getattr(full, "_mi_fp8_sink", None)
+            s = None if fs is None else (fs[0], fs[1] + sr0, sn)
         if s is None or not p.is_contiguous() or p.dim() != 2:
             return None
         sink, r0, n = s
@@ -142,9 +147,18 @@ class ClippedAdamW(torch.optim.Optimizer):
             for gi, plan in plans:
                 _lib.check(lib.mi_sumsq_bf16_multi(plan["table"].data_ptr(), len(gi), plan["chunks"].data_ptr(), plan["n_chunks"],
                                                    self.CHUNK, plan["partials"].data_ptr(), st), "mi_sumsq_bf16_multi")
-            total = plans[0][1]["partials"].sum(dtype=torch.float32)
-            for _, plan in plans[1:]:
-                total = total + plan["partials"].sum(dtype=torch.float32)
+            total = shard_total = None
+            for gi, plan in plans:
+                t = plan["partials"].sum(dtype=torch.float32)
+                if gi[0][0].get("sharded", False):  # row shards of ShardedFP8DP: every rank holds different rows
+                    shard_total = t if shard_total is None else shard_total + t
+                else:
+                    total = t if total is None else total + t
+            if shard_total is not None:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                    dist.all_reduce(shard_total, op=dist.ReduceOp.SUM)
+                total = shard_total if total is None else total + shard_total
             total = total.sqrt()
             self.last_grad_norm = total
             coef = (self.max_grad_norm / (total + 1e-6)).clamp(max=1.0).reshape(1)  # clip_grad_norm_'s coefficient

@@ -152,9 +152,12 @@ def _cast_weights(spec: _GemmSpec, g: int, weights, ns, N: int, K: int, dev, nee
             return hit
     # (no grad-mode test here: inside an autograd Function's forward grad mode is always off; fresh copies are the bytes a
     # cast would produce now in any mode)
-    if spec.wcache is not None and spec.training and spec.fmt_fwd == 0 and weight_sinks_enabled():
+    if spec.wcache is not None and spec.fmt_fwd == 0 and weight_sinks_enabled():
         sink = spec.wcache.get(("sink", g))
-        if sink is None or sink.arena is not mf.arena or len(sink.parts) != len(weights) or any(a is not b for (a, _, _), b in zip(sink.parts, weights)):
+        stale = sink is None or sink.arena is not mf.arena or len(sink.parts) != len(weights) or any(a is not b for (a, _, _), b in zip(sink.parts, weights))
+        if stale and not spec.training:
+            sink = None  # sinks are created by training passes only; an evaluation pass may USE a fresh one (same bytes)
+        elif stale:
             if all(w.dtype == torch.bfloat16 and w.is_contiguous() and w.dim() == 2 and w.shape[1] == K and isinstance(w, torch.nn.Parameter)
                    for w in weights) and N % 8 == 0 and K % 8 == 0:
                 sink = spec.wcache[("sink", g)] = WeightSink(weights, ns, N, K, dev, mf, 3 * g + 1)

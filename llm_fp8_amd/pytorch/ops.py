@@ -316,6 +316,18 @@ def mxfp8_rope_bwd_quantize(dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor
     return y_row, s_row, y_colT, s_colT
 
 
+def transpose_u8(y: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """FP8 bytes [R, C] -> [C, R] (mi_transpose_u8); rows / cols multiples of 8; `out` may be a strided [C, R] view."""
+    _dev(y)
+    assert y.dtype == torch.uint8 and y.dim() == 2 and y.stride(1) == 1
+    R, C = y.shape
+    if out is None:
+        out = torch.empty((C, R), dtype=torch.uint8, device=y.device)
+    assert out.shape == (C, R) and out.dtype == torch.uint8 and out.stride(1) == 1
+    _lib.check(_lib.load().mi_transpose_u8(y.data_ptr(), out.data_ptr(), R, C, y.stride(0), out.stride(0), _stream()), "mi_transpose_u8")
+    return out
+
+
 def embedding_grad_add_(grad: torch.Tensor, dy: torch.Tensor, ids: torch.Tensor, alpha: float = 1.0, padding_idx: int = -1) -> None:
     """grad [V, H] bf16 += alpha * scatter-sum of dy [T, H] bf16 rows by ids [T] (int64), in place, deterministic."""
     _dev(grad, dy, ids)

@@ -82,6 +82,7 @@ def create_model(cfg: TrainingConfig, device) -> torch.nn.Module:
 def save_model(model, cfg: TrainingConfig, layout: str = "hf"):
     """ModelSaver.save_model (train_fp8.py:657-681) without the tokenizer (unreachable offline): config.json + safetensors."""
     from . import checkpoint
+    # (under ShardedFP8DP the caller runs model.gather_master_weights() on EVERY rank first -- it is a collective; main() does)
     return checkpoint.save_pretrained(checkpoint.unwrap(model), cfg.output_dir, layout=layout, save_fp8_state=True)
 
 
@@ -144,6 +145,11 @@ def wrap_distributed(model: torch.nn.Module, cfg: TrainingConfig, device) -> tor
     if mode == "replicated":
         from .distributed import GradArenaDP
         return GradArenaDP(model, bucket_mb=float(os.environ.get("LLM_FP8_AMD_BUCKET_MB", "256")))
+    if mode == "fsdp_fp8":
+        # FULL_SHARD counterpart with an FP8 all-gather (distributed.ShardedFP8DP): optimiser state, update and weight cast
+        # row-sharded; 1 byte per parameter gathered per step instead of FSDP's two bf16 gathers
+        from .distributed import ShardedFP8DP
+        return ShardedFP8DP(model, bucket_mb=float(os.environ.get("LLM_FP8_AMD_BUCKET_MB", "256")))
     if mode == "ddp":
         from torch.nn.parallel import DistributedDataParallel as DDP
         return DDP(model, device_ids=[device.index] if device.type == "cuda" else None, gradient_as_bucket_view=True)
@@ -164,13 +170,14 @@ def wrap_distributed(model: torch.nn.Module, cfg: TrainingConfig, device) -> tor
 def create_optimizer(model, cfg: TrainingConfig):
     """AdamW(fused=True) + linear warmup/decay (train_fp8.py:200-210).  On the single-GPU path (bf16 parameters on the
     device, no FSDP/DDP wrapper) the clip + AdamW pair runs as `ClippedAdamW` (two HIP passes, same update rule)."""
-    params = [p for p in model.parameters() if p.requires_grad]
+    groups = model.optimizer_param_groups() if hasattr(model, "optimizer_param_groups") else None
+    params = [p for g in groups for p in g["params"]] if groups is not None else [p for p in model.parameters() if p.requires_grad]
     fused = all(p.is_cuda for p in params)
     wrapped = type(model).__name__ in ("FullyShardedDataParallel", "DistributedDataParallel")
     if (fused and not wrapped and all(p.dtype == torch.bfloat16 for p in params)
             and os.environ.get("LLM_FP8_AMD_TORCH_ADAMW") != "1"):
         from .optim import ClippedAdamW
-        opt = ClippedAdamW(params, lr=cfg.learning_rate, max_grad_norm=cfg.max_grad_norm)
+        opt = ClippedAdamW(groups if groups is not None else params, lr=cfg.learning_rate, max_grad_norm=cfg.max_grad_norm)
     else:
         opt = torch.optim.AdamW(params, lr=cfg.learning_rate, fused=fused)
 
@@ -226,6 +233,8 @@ def train_step(model, batch, optimizer, scheduler, cfg: TrainingConfig):
     else:
         torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.max_grad_norm)
     optimizer.step()
+    if hasattr(model, "after_optimizer_step"):
+        model.after_optimizer_step()  # ShardedFP8DP: FP8 all-gather of the freshly quantised weight shards
     scheduler.step()
     optimizer.zero_grad()
     return total if n > 1 else loss
@@ -309,9 +318,12 @@ def main(argv=None):
         if rank == 0:
             toks = cfg.batch_size * cfg.max_seq_length * world * acc / dt  # train_multi_gpu.py:751-755
             print(json.dumps({"step": step, "loss": lv, "ms": dt * 1e3, "tokens_per_s": toks}), flush=True)
-    if cfg.output_dir and rank == 0:
-        files = save_model(model, cfg, a.save_layout)
-        print(json.dumps({"saved": files}), flush=True)
+    if cfg.output_dir:
+        if hasattr(model, "gather_master_weights"):
+            model.gather_master_weights()  # a collective: every rank takes part, rank 0 writes
+        if rank == 0:
+            files = save_model(model, cfg, a.save_layout)
+            print(json.dumps({"saved": files}), flush=True)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,57 @@
+"""Worker of tests/test_distributed_gpu.py::test_sharded_fp8_dp_*: launched by torch.distributed.run.  distributed.ShardedFP8DP
+(`--sharding_mode fsdp_fp8`: row-sharded optimiser + weight cast, FP8 all-gather) against distributed.GradArenaDP (`replicated`)
+on the same data: same averaged gradients, same AdamW arithmetic on every row, same FP8 bytes -- so the losses of every step and
+the final master weights (after gather_master_weights) must be IDENTICAL.  Prints one JSON line per rank."""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from llm_fp8_amd import train  # noqa: E402
+from llm_fp8_amd.pytorch.fp8 import FP8GlobalStateManager as G  # noqa: E402
+
+
+def run(mode, scenario, rank, device, steps=4):
+    G.reset()
+    cfg = train.TrainingConfig(model_name="llama-3.2-1b", batch_size=4, max_seq_length=128, mixed_precision="fp8",
+                               fp8_scenario=scenario, use_te=True, sharding_mode=mode, num_hidden_layers=2,
+                               vocab_size=4096, learning_rate=1e-3, num_warmup_steps=0)
+    torch.manual_seed(4321)
+    model = train.prepare_model(train.create_model(cfg, device), cfg)
+    dp = train.wrap_distributed(model, cfg, device)
+    opt, sched = train.create_optimizer(dp, cfg)
+    dp.train()
+    gen = torch.Generator(device=device).manual_seed(70 + rank)
+    losses = [train.train_step(dp, train.synthetic_batch(cfg, 4096, device, gen), opt, sched, cfg).item() for _ in range(steps)]
+    # an evaluation pass (FP8 still on inside the layers, as in the reference): must run on the gathered FP8 copies, not on stale masters
+    dp.eval()
+    with torch.no_grad():
+        ev = dp(**train.synthetic_batch(cfg, 4096, device, torch.Generator(device=device).manual_seed(5))).loss.item()
+    dp.train()
+    if hasattr(dp, "gather_master_weights"):
+        dp.gather_master_weights()
+    flat = torch.cat([p.detach().reshape(-1).view(torch.int16) for p in model.parameters()]).clone()
+    info = dp.describe()
+    moments = sum(st["exp_avg"].numel() for st in opt.state.values())
+    del dp, opt, model
+    torch.cuda.empty_cache()
+    return losses, ev, flat, type(opt).__name__ if False else "ClippedAdamW", info, moments
+
+
+def main():
+    scenario = sys.argv[1]
+    rank, local, world, device = train.setup_distributed()
+    l_rep, e_rep, w_rep, _, _, mom_rep = run("replicated", scenario, rank, device)
+    l_sh, e_sh, w_sh, _, info, mom_sh = run("fsdp_fp8", scenario, rank, device)
+    print(json.dumps({"rank": rank, "world": world, "losses_equal": l_rep == l_sh, "eval_equal": e_rep == e_sh,
+                      "weights_equal": bool(torch.equal(w_rep, w_sh)), "losses": l_sh, "losses_rep": l_rep, "eval": [e_rep, e_sh],
+                      "sharded_weights": info.get("sharded_weights", 0), "moment_elems": [mom_rep, mom_sh]}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
