@@ -119,7 +119,7 @@ def gemm_clock_probe(sites, top: int = 4):
     tot_w = tot = 0.0
     per_site = {}
     for tag, v in sorted(sites.items(), key=lambda kv: -kv[1]["seconds"])[:top]:
-        m, n, k = (int(t) for t in tag.split("x"))
+        m, n, k = (int(t) for t in tag.split("+")[0].split("x"))  # a grouped launch "AxBxC+DxExF": probe its first problem
         if (m % 256 and m % 192) or (n % 256 and n % 192) or k % 256 or m * k >= 2 ** 31 or n * k >= 2 ** 31 or m * n * 2 >= 2 ** 31:
             continue
         a = torch.randint(0, 256, (m, k), generator=g, device=dev, dtype=torch.uint8)

@@ -53,7 +53,8 @@ extern "C" {
  * mi_abi_version() returns the value the library was built with; a binding compares it with the header it was written
  * against (llm_fp8_amd/_lib.py does at load time).
  *   1  round 1 (the surface of SURVEY.md 8b + fused neighbours)
- *   2  round 2: mi_gemm_fp8 algo values 20-24, 46 (diagnostic builds), mi_adamw_cast_bf16_multi, mi_transpose_u8
+ *   2  round 2: mi_gemm_fp8 algo values 20-24, 46 (diagnostic builds), mi_adamw_cast_bf16_multi, mi_transpose_u8,
+ *      mi_gemm_fp8_grouped
  */
 #define MI_ABI_VERSION 2
 int mi_abi_version(void);
@@ -118,6 +119,24 @@ int mi_scale_update(float* amax_history, float* scale, float* scale_inv, const f
 int mi_gemm_fp8(const void* A, const void* B, void* D, const float* sa_inv, const float* sb_inv,
                 const void* bias_bf16, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                 int64_t ldd, int fmt_a, int fmt_b, int out_dtype, int algo, void* stream);
+
+/*
+ * Grouped form of mi_gemm_fp8: up to 4 independent problems D_p = (A_p . B_p^T) * (*sa_inv_p * *sb_inv_p), bf16 outputs, no
+ * bias, in ONE persistent launch whose workgroups walk a shared tile list (longest tiles first) -- a Linear's dgrad + wgrad
+ * (both consume the same grad_output) pay one ramp and one exposed epilogue, and the short problem's tiles fill
+ * the idle part of the long one's last round of tiles.  All problems share fmt_a / fmt_b and the tile shape: tile_cfg
+ * 0 = 256x256, 1 = 256x192, 2 = 192x256, 3 = 192x192, -1 = choose (M_p, N_p must be multiples of the tile, K_p of 256;
+ * operands below 2 GiB; at most 64 tiles per workgroup).  Results are bitwise those of mi_gemm_fp8(algo 4) per problem.
+ */
+typedef struct mi_gemm_problem {
+  const void* A;        /* fp8 [M, K], row stride lda */
+  const void* B;        /* fp8 [N, K], row stride ldb */
+  void* D;              /* bf16 [M, N], row stride ldd */
+  const float* sa_inv;  /* device scalars */
+  const float* sb_inv;
+  int64_t M, N, K, lda, ldb, ldd;
+} mi_gemm_problem;
+int mi_gemm_fp8_grouped(const mi_gemm_problem* problems, int n, int fmt_a, int fmt_b, int tile_cfg, void* stream);
 
 /*
  * Stream-K workspace for the persistent GEMM, used only by the explicit algo 44: when the 256x256 tile count is not a

@@ -16,6 +16,13 @@ _c_i64 = ctypes.c_int64
 _c_int = ctypes.c_int
 _p = ctypes.c_void_p
 
+class GemmProblem(ctypes.Structure):
+    """include/mi_fp8.h `mi_gemm_problem`."""
+    _fields_ = [("A", ctypes.c_void_p), ("B", ctypes.c_void_p), ("D", ctypes.c_void_p), ("sa_inv", ctypes.c_void_p),
+                ("sb_inv", ctypes.c_void_p), ("M", ctypes.c_int64), ("N", ctypes.c_int64), ("K", ctypes.c_int64),
+                ("lda", ctypes.c_int64), ("ldb", ctypes.c_int64), ("ldd", ctypes.c_int64)]
+
+
 # name -> argtypes (all return int unless noted); mirrors include/mi_fp8.h exactly
 SIGNATURES = {
     "mi_abi_version": [],
@@ -24,6 +31,7 @@ SIGNATURES = {
     "mi_cast_amax": [_p, _p, _p, _p, _p, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _p],
     "mi_transpose_u8": [_p, _p, _c_i64, _c_i64, _c_i64, _c_i64, _p],
     "mi_scale_update": [_p, _p, _p, _p, _c_int, _c_int, _c_i64, _c_int, _c_int, _p],
+    "mi_gemm_fp8_grouped": [_p, _c_int, _c_int, _c_int, _c_int, _p],
     "mi_gemm_fp8": [_p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64,
                     _c_int, _c_int, _c_int, _c_int, _p],
     "mi_mxfp8_quantize": [_p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],

@@ -247,6 +247,34 @@ def _wgrad_out(weights, K: int) -> Optional[torch.Tensor]:
     return arena[off:end].view(-1, K)
 
 
+def _dgrad_wgrad(g8, wt8, g8t, xt8, sig, si_w, si_x, fmt_b: int, fmt_f: int, dw_out, need_dgrad: bool, need_wgrad: bool):
+    """A Linear's two backward GEMMs on one grad_output: dX [M, K] = G8 [M, N] . W8T [K, N]^T and dW [N, K] = G8T [N, M] . X8T [K, M]^T.
+    ONE grouped persistent launch (ops.gemm_fp8_grouped) where it measures faster (ops.grouped_gemm_autotune, once per shape) --
+    one ramp, one exposed epilogue, and the short problem's tiles fill the idle part of the long one's last round -- else two
+    launches.  Bitwise the
+    same results either way.  (Under torch.distributed the GEMMs run one workgroup per tile so that RCCL's kernels get CUs:
+    no persistent grouping there.)"""
+    dx = dw = None
+    if need_dgrad and need_wgrad and ops.default_gemm_algo() in (0, 4) and os.environ.get("LLM_FP8_AMD_NO_GROUPED_GEMM") != "1":
+        M, N = g8.shape
+        K = wt8.shape[0]
+        if (ops.grouped_gemm_ok(((M, K, N), (N, K, M))) and g8.stride(1) == 1 and wt8.stride(1) == 1 and g8t.stride(1) == 1
+                and xt8.stride(1) == 1):
+            dx = torch.empty((M, K), dtype=torch.bfloat16, device=g8.device)
+            dw = dw_out if dw_out is not None else torch.empty((N, K), dtype=torch.bfloat16, device=g8.device)
+            probs = [(g8, wt8, sig, si_w, dx), (g8t, xt8, sig, si_x, dw)]
+            cfg = ops.grouped_gemm_autotune(probs, fmt_b, fmt_f)  # measured once per shape: -1 = two launches are faster here
+            if cfg >= 0:
+                ops.gemm_fp8_grouped(probs, fmt_b, fmt_f, tile_cfg=cfg)
+                return dx, dw
+            dx = dw = None
+    if need_dgrad:
+        dx = ops.gemm_fp8(g8, wt8, sig, si_w, fmt_b, fmt_f)
+    if need_wgrad:
+        dw = ops.gemm_fp8(g8t, xt8, sig, si_x, fmt_b, fmt_f, out=dw_out)
+    return dx, dw
+
+
 def _skip_2d(dskip: Optional[torch.Tensor], like: torch.Tensor) -> Optional[torch.Tensor]:
     """Residual-branch gradient as a contiguous bf16 [tokens, features] matrix for mi_rmsnorm_bwd's `dres`."""
     if dskip is None:
@@ -355,10 +383,8 @@ class _FP8LinearFn(torch.autograd.Function):
                 g8, g8t = ops.cast_amax(g2, mb.scale(2 * g), mb.amax(2 * g), spec.fmt_bwd,
                                         want_y=ctx.need_dgrad, want_t=ctx.need_wgrad)
             sig = mb.scale_inv(2 * g)
-            if ctx.need_dgrad:
-                dx = ops.gemm_fp8(g8, wt8, sig, sinv[1], spec.fmt_bwd, spec.fmt_fwd)
-            if ctx.need_wgrad:
-                dw = ops.gemm_fp8(g8t, xt8, sig, sinv[0], spec.fmt_bwd, spec.fmt_fwd, out=_wgrad_out(ctx.w_refs, xt8.shape[0]))
+            dx, dw = _dgrad_wgrad(g8, wt8, g8t, xt8, sig, sinv[1], sinv[0], spec.fmt_bwd, spec.fmt_fwd,
+                                  _wgrad_out(ctx.w_refs, xt8.shape[0]) if ctx.need_wgrad else None, ctx.need_dgrad, ctx.need_wgrad)
         db = None
         if ctx.has_bias:
             db = db_fused if db_fused is not None else g2.sum(0, dtype=torch.float32).to(ctx.bias_dtype)
@@ -505,15 +531,15 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
         else:
             g8, g8t = ops.cast_amax(g2, mb.scale(2), mb.amax(2), fmt_b, want_t=ctx.need_w)
             db2 = None
-        dact = ops.gemm_fp8(g8, w2_8t, mb.scale_inv(2), sinv[3], fmt_b, fmt_f)
-        dw2 = ops.gemm_fp8(g8t, a8t, mb.scale_inv(2), sinv[2], fmt_b, fmt_f, out=_wgrad_out(ctx.w_refs[1:], a8t.shape[0])) if ctx.need_w else None
+        dact, dw2 = _dgrad_wgrad(g8, w2_8t, g8t, a8t, mb.scale_inv(2), sinv[3], sinv[2], fmt_b, fmt_f,
+                                 _wgrad_out(ctx.w_refs[1:], a8t.shape[0]) if ctx.need_w else None, True, ctx.need_w)
         # dSwiGLU + cast of fc1's grad_output (GEMM index 0: bwd slot 0) + fc1 bias gradient
         want_b1 = ctx.dtypes[1] is not None
         dh8, dh8t, colsum = ops.dswiglu_cast(h, dact, mb.scale(0), mb.amax(0), fmt_b, want_y=ctx.need_dgrad,
                                              want_t=ctx.need_w, want_colsum=want_b1)
         db1 = (colsum, ctx.dtypes[1]) if want_b1 else None
-        dx = ops.gemm_fp8(dh8, w1_8t, mb.scale_inv(0), sinv[1], fmt_b, fmt_f) if ctx.need_dgrad else None
-        dw1 = ops.gemm_fp8(dh8t, x8t, mb.scale_inv(0), sinv[0], fmt_b, fmt_f, out=_wgrad_out(ctx.w_refs[:1], x8t.shape[0])) if ctx.need_w else None
+        dx, dw1 = _dgrad_wgrad(dh8, w1_8t, dh8t, x8t, mb.scale_inv(0), sinv[1], sinv[0], fmt_b, fmt_f,
+                                _wgrad_out(ctx.w_refs[:1], x8t.shape[0]) if ctx.need_w else None, ctx.need_dgrad, ctx.need_w)
         return _FP8SwiGLUMLPFn._finish_backward(ctx, dx, dw1, db1, dw2, db2, dskip)
 
     @staticmethod

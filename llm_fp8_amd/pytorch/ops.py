@@ -2,6 +2,7 @@
 function raises if handed a CPU tensor -- there is no PyTorch/CPU fallback for this path."""
 from __future__ import annotations
 
+import ctypes
 import os
 from typing import Optional, Tuple
 
@@ -314,6 +315,141 @@ def mxfp8_rope_bwd_quantize(dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor
             rc = _lib.load().mi_mxfp8_rope_bwd_quantize(*args)
     _lib.check(rc, "mi_mxfp8_rope_bwd_quantize")
     return y_row, s_row, y_colT, s_colT
+
+
+def gemm_fp8_grouped(problems, fmt_a: int, fmt_b: int, tile_cfg: int = -1) -> None:
+    """ONE persistent launch for up to 4 GEMMs D = (A . B^T) * (sa_inv * sb_inv) (mi_gemm_fp8_grouped): `problems` is a list of
+    (a8 [M,K], b8 [N,K], sa_inv, sb_inv, out bf16 [M,N]); all share the operand formats.  Outputs are written in place."""
+    n = len(problems)
+    arr = (_lib.GemmProblem * n)()
+    for i, (a8, b8, sa, sb, out) in enumerate(problems):
+        _dev(a8, b8, sa, sb, out)
+        assert a8.dtype == torch.uint8 and b8.dtype == torch.uint8 and out.dtype == torch.bfloat16
+        assert a8.stride(1) == 1 and b8.stride(1) == 1 and out.stride(1) == 1 and a8.shape[1] == b8.shape[1]
+        assert out.shape == (a8.shape[0], b8.shape[0])
+        arr[i] = _lib.GemmProblem(a8.data_ptr(), b8.data_ptr(), out.data_ptr(), sa.data_ptr(), sb.data_ptr(), a8.shape[0], b8.shape[0],
+                                  a8.shape[1], a8.stride(0), b8.stride(0), out.stride(0))
+    t = KernelTimer.active
+    if t is None:
+        rc = _lib.load().mi_gemm_fp8_grouped(ctypes.byref(arr), n, fmt_a, fmt_b, tile_cfg, _stream())
+    else:
+        work = sum(2.0 * a.shape[0] * b.shape[0] * a.shape[1] for a, b, _, _, _ in problems)
+        nbytes = sum(a.numel() + b.numel() + 2 * o.numel() for a, b, _, _, o in problems)
+        tag = "+".join(f"{a.shape[0]}x{b.shape[0]}x{a.shape[1]}" for a, b, _, _, _ in problems)
+        with t.span("gemm_fp8", tag, work, nbytes):
+            rc = _lib.load().mi_gemm_fp8_grouped(ctypes.byref(arr), n, fmt_a, fmt_b, tile_cfg, _stream())
+    _lib.check(rc, "mi_gemm_fp8_grouped")
+
+
+def grouped_gemm_ok(shapes, strides_ok: bool = True) -> bool:
+    """Can mi_gemm_fp8_grouped take these (M, N, K) problems together?  (one tile shape dividing all, K % 256, < 2 GiB operands)"""
+    if not strides_ok or not shapes or len(shapes) > 4:
+        return False
+    if not any(all(M % bm == 0 and N % bn == 0 for M, N, K in shapes) for bm, bn in _TILE_CFGS):
+        return False
+    if any(K % 256 or M * K >= 2 ** 31 or N * K >= 2 ** 31 or M * N * 2 >= 2 ** 31 for M, N, K in shapes):
+        return False
+    return True
+
+
+_TILE_CFGS = ((256, 256), (256, 192), (192, 256), (192, 192))
+_TILE_EFF = (1.0, 0.90, 0.90, 0.80)   # relative MFMA-time efficiency of the shorter phases (mi_gemm.hip pick_tile_cfg)
+_GROUP_PLAN: dict = {}
+
+
+def grouped_gemm_plan(shapes, n_cu: int = 256) -> int:
+    """Tile shape (0-3) with which ONE grouped launch of these (M, N, K) problems is predicted to beat separate launches, or -1.
+    Model, in K-tile steps of a 256 x 256 tile: separate = sum over problems of rounds x K-tiles x area / efficiency at the
+    problem's best tile shape, + a fixed cost per launch (ramp + exposed last epilogue ~ 4 steps); grouped = the makespan of the
+    longest-processing-time schedule the library builds (same greedy, here on counts), x 1.02 for the slightly heavier kernel,
+    + one fixed cost.  Calibrated on tools/bench_kernels.py --which grouped (MI355X): grouped wins where the short problem fills
+    the long one's last round (Llama-3.2-3B fc1 / fc2 / o-proj / lm_head backward: +4..10 %), not where the tile counts
+    already divide the chip (3B q|k|v, 8B o-proj: -6 %)."""
+    key = (tuple(shapes), n_cu)
+    if key in _GROUP_PLAN:
+        return _GROUP_PLAN[key]
+    import heapq
+    best = -1
+    if grouped_gemm_ok(shapes):
+        fixed = 4.0
+        sep = 0.0
+        for M, N, K in shapes:
+            c = min((-(-((M // bm) * (N // bn)) // n_cu)) * (K // 128) * (bm * bn / 65536.0) / eff
+                    for (bm, bn), eff in zip(_TILE_CFGS, _TILE_EFF) if M % bm == 0 and N % bn == 0)
+            sep += c + fixed
+        best_cost = None
+        for cfg, ((bm, bn), eff) in enumerate(zip(_TILE_CFGS, _TILE_EFF)):
+            if any(M % bm or N % bn for M, N, K in shapes):
+                continue
+            probs = sorted(((K // 128, (M // bm) * (N // bn)) for M, N, K in shapes), reverse=True)
+            total = sum(t for _, t in probs)
+            g = min(total, n_cu)
+            loads = [(0, v) for v in range(g)]
+            heapq.heapify(loads)
+            per_wg = [0] * g
+            for nk, tiles in probs:
+                for _ in range(tiles):
+                    load, v = heapq.heappop(loads)
+                    per_wg[v] += 1
+                    heapq.heappush(loads, (load + nk, v))
+            if max(per_wg) > 64:
+                continue
+            cost = max(l for l, _ in loads) * (bm * bn / 65536.0) / eff * 1.02 + fixed
+            if best_cost is None or cost < best_cost:
+                best_cost, best = cost, cfg
+        if best_cost is None or best_cost >= 0.98 * sep:
+            best = -1
+    _GROUP_PLAN[key] = best
+    return best
+
+
+_GROUP_TUNED: dict = {}
+
+
+def grouped_gemm_autotune(problems, fmt_a: int, fmt_b: int, iters: int = 3) -> int:
+    """Measured choice for a recurring group of GEMMs (a Linear's dgrad + wgrad): -1 = separate launches, 0-3 = one grouped launch
+    with that tile shape.  Timed once per (shapes, formats) on the operands at hand -- every candidate writes bitwise the same
+    outputs, so re-running them is harmless -- and cached.  The model (grouped_gemm_plan) ranks the same candidates from counts
+    alone; the measurement also sees what the model leaves out (per-tile epilogue cost, L2 behaviour, clock)."""
+    shapes = tuple((a.shape[0], b.shape[0], a.shape[1]) for a, b, _, _, _ in problems)
+    key = (shapes, fmt_a, fmt_b)
+    hit = _GROUP_TUNED.get(key)
+    if hit is not None:
+        return hit
+    cands = {-1: None}
+    if grouped_gemm_ok(shapes):
+        for cfg, (bm, bn) in enumerate(_TILE_CFGS):
+            if all(M % bm == 0 and N % bn == 0 for M, N, K in shapes):
+                cands[cfg] = cfg
+
+    def run(c):
+        if c == -1:
+            for a8, b8, sa, sb, out in problems:
+                gemm_fp8(a8, b8, sa, sb, fmt_a, fmt_b, out=out, algo=4)
+        else:
+            gemm_fp8_grouped(problems, fmt_a, fmt_b, tile_cfg=c)
+
+    saved, KernelTimer.active = KernelTimer.active, None  # (the candidates are not part of any timed span)
+    try:
+        best, best_t = -1, None
+        for c in cands:
+            try:
+                run(c)
+            except RuntimeError:
+                continue
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                run(c)
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if best_t is None or t < best_t * (0.98 if c != -1 and best == -1 else 1.0):
+                best, best_t = c, t
+    finally:
+        KernelTimer.active = saved
+    _GROUP_TUNED[key] = best
+    return best
 
 
 def transpose_u8(y: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

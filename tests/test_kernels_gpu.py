@@ -839,3 +839,58 @@ def test_mxfp8_full_size_properties(ops, dev):
     d = ops.gemm_mxfp8(a8, sa, b8, sb)
     rms = ref.pow(2).mean().sqrt().item()
     assert ((d.float() - ref).abs() <= 2.0 ** -7 * ref.abs() + 2e-3 * rms).all()
+
+
+# ----------------------------------------------------------------------------------------- grouped GEMM (dgrad + wgrad in one launch)
+GROUPS = [
+    [(512, 768, 256), (768, 256, 512)],                       # a Linear's dgrad [M,K_w] and wgrad [N_w,K_w]: K 256 vs 512
+    [(2048, 768, 1024), (1024, 768, 2048)],                   # 192-column tiles
+    [(4096, 3072, 3072), (3072, 3072, 4096)],                 # o-proj backward at M = 4096: > 1 round, mixed K
+    [(1536, 1536, 256), (768, 384, 1024), (384, 1920, 512)],  # three problems, 192 x 192 tiles
+    [(8192, 3072, 8192), (8192, 3072, 8192)],                 # fc2 backward of Llama-3.2-3B at full size
+    [(256, 256, 256)],                                        # a single problem, a single tile
+]
+
+
+@pytest.mark.parametrize("group", GROUPS)
+@pytest.mark.parametrize("fa,fb", [(O.E4M3, O.E4M3), (O.E5M2, O.E4M3)])
+def test_grouped_gemm_is_bitwise_the_separate_launches(ops, dev, group, fa, fb):
+    """mi_gemm_fp8_grouped: every problem's output must be BIT FOR BIT what mi_gemm_fp8 (persistent kernel) gives for it alone
+    (same MFMA order per output element), whatever the tile shape chosen for the group; small problems also vs the oracle."""
+    g = torch.Generator(device=dev).manual_seed(len(group) * 7 + fa)
+    probs, refs = [], []
+    for (M, N, K) in group:
+        a8 = torch.randint(0, 256, (M, K), generator=g, device=dev, dtype=torch.uint8)
+        b8 = torch.randint(0, 256, (N, K), generator=g, device=dev, dtype=torch.uint8)
+        for t, f in ((a8, fa), (b8, fb)):
+            if f == O.E4M3:
+                t[(t & 0x7F) >= 0x68] &= 0xBF
+            else:
+                t[(t & 0x7F) >= 0x54] &= 0xCF
+        sa = torch.rand(1, generator=g, device=dev) + 0.5
+        sb = torch.rand(1, generator=g, device=dev) * 0.01 + 0.001
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        probs.append((a8, b8, sa, sb, out))
+    ops.gemm_fp8_grouped(probs, fa, fb)
+    for cfg in (-1, 3):  # the chosen tile shape and, where it divides everything, the 192 x 192 one
+        if cfg == 3 and any(M % 192 or N % 192 for M, N, K in group):
+            continue
+        if cfg == 3:
+            for p in probs:
+                p[4].fill_(float("nan"))
+            ops.gemm_fp8_grouped(probs, fa, fb, tile_cfg=3)
+        for (a8, b8, sa, sb, out), (M, N, K) in zip(probs, group):
+            alone = ops.gemm_fp8(a8, b8, sa, sb, fa, fb, algo=4)
+            assert torch.equal(out.view(torch.int16), alone.view(torch.int16)), f"problem {M}x{N}x{K} (tile cfg {cfg}) differs from its own launch"
+            if M * N * K <= 768 * 1024 * 1024:
+                ref = O.gemm_fp8_tn(a8.cpu().numpy(), b8.cpu().numpy(), fa, fb, np.float32(sa.item()), np.float32(sb.item()), None, out_f32=True)
+                assert_gemm_close(out.float().cpu().numpy(), ref, f"grouped {M}x{N}x{K}")
+
+
+def test_grouped_gemm_rejects_what_it_cannot_take(ops, dev):
+    a = torch.zeros((256, 128), dtype=torch.uint8, device=dev)  # K = 128: not a multiple of 256
+    o = torch.empty((256, 256), dtype=torch.bfloat16, device=dev)
+    one = torch.ones(1, device=dev)
+    with pytest.raises(RuntimeError, match="does not fit tile shape|no tile shape"):
+        ops.gemm_fp8_grouped([(a, a, one, one, o)], 0, 0)
+    assert not ops.grouped_gemm_ok([(256, 256, 128)]) and ops.grouped_gemm_ok([(8192, 3072, 3072), (3072, 3072, 8192)])

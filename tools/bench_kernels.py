@@ -206,6 +206,32 @@ def main():
                     print(f"abbase {mname} {name:4s} {kind:5s} {m}x{n}x{k}: base {res['base']*1e6:7.1f} us {fl/res['base']/1e12:6.0f} TF   cur {res['cur']*1e6:7.1f} us "
                           f"{fl/res['cur']/1e12:6.0f} TF   {res['base']/res['cur']:.3f}x", flush=True)
             print(f"abbase {mname} decoder-layer GEMM time: base {tb*1e6:8.1f} us  cur {tc*1e6:8.1f} us  {tb/tc:.3f}x", flush=True)
+    if "grouped" in args.which:  # a Linear's dgrad + wgrad: two launches vs mi_gemm_fp8_grouped, interleaved A/B
+        models = {"3b": (8192, {"qkv": (5120, 3072), "o": (3072, 3072), "fc1": (16384, 3072), "fc2": (3072, 8192), "lm_head": (128256, 3072)}),
+                  "1b": (8192, {"qkv": (3072, 2048), "o": (2048, 2048), "fc1": (16384, 2048), "fc2": (2048, 8192)}),
+                  "8b": (6144, {"qkv": (6144, 4096), "o": (4096, 4096), "fc1": (28672, 4096), "fc2": (4096, 14336)})}
+        for mname in os.environ.get("MODELS", "3b").split(","):
+            M, sites = models[mname]
+            tsep = tgrp = 0.0
+            for name, (N, K) in sites.items():
+                g8, w8t = rand_fp8((M, N), dev, g), rand_fp8((K, N), dev, g)      # dgrad: dX[M,K] = G8[M,N] . W8T[K,N]^T
+                g8t, x8t = rand_fp8((N, M), dev, g), rand_fp8((K, M), dev, g)    # wgrad: dW[N,K] = G8T[N,M] . X8T[K,M]^T
+                dx = torch.empty((M, K), dtype=torch.bfloat16, device=dev)
+                dw = torch.empty((N, K), dtype=torch.bfloat16, device=dev)
+                if not ops.grouped_gemm_ok([(M, K, N), (N, K, M)]):
+                    print(f"grouped {mname} {name}: not eligible", flush=True)
+                    continue
+                def sep():
+                    ops.gemm_fp8(g8, w8t, one, one, 0, 0, out=dx, algo=4)
+                    ops.gemm_fp8(g8t, x8t, one, one, 0, 0, out=dw, algo=4)
+                def grp():
+                    ops.gemm_fp8_grouped([(g8, w8t, one, one, dx), (g8t, x8t, one, one, dw)], 0, 0)
+                res = time_interleaved({"separate": sep, "grouped": grp}, rounds=10, inner=4)
+                fl = 4.0 * M * N * K
+                tsep += res["separate"]; tgrp += res["grouped"]
+                print(f"grouped {mname} {name:7s} bwd M={M} N={N} K={K}: separate {res['separate']*1e6:7.1f} us {fl/res['separate']/1e12:6.0f} TF   "
+                      f"grouped {res['grouped']*1e6:7.1f} us {fl/res['grouped']/1e12:6.0f} TF   {res['separate']/res['grouped']:.3f}x", flush=True)
+            print(f"grouped {mname} total: separate {tsep*1e6:8.1f} us  grouped {tgrp*1e6:8.1f} us  {tsep/tgrp:.3f}x", flush=True)
     if "clock" in args.which:
         from llm_fp8_amd import _lib
         lib = _lib.load()
