@@ -502,29 +502,58 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
 
   // per-lane staging offsets.  Half-tile local row -> tile row: the rows of wave-row wr' (A) / wave-col wc' (B) of
   // half h are contiguous in the tile, so a wave's output block is contiguous (whole 128-B lines per row).
-  int a0_voff[2], a1_voff[nA1], b0_voff[2], b1_voff[nB1];
+  // ONE per-lane offset per operand (plus one for a second half whose row map differs: MA1 == 2 / NB1 == 1); the second
+  // 8-row piece of a wave and the second half of the tile are wave-uniform distances from it and ride in the SGPR offset of
+  // the buffer load.  (Eight separate per-lane offsets pushed the 256x256 variants over the 256-VGPR limit: a spilled
+  // fragment base was reloaded behind `s_waitcnt vmcnt(0)` once per tile, draining the prefetch pipeline.)
+  int a0_v, b0_v, a1_v = 0, b1_v = 0;
   {
     const int lr = lane >> 3, lc = lane & 7;
     const int chunk = (lc ^ swz_f(lr)) * 16;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int local = (wave * 2 + i) * 8 + lr;  // half 0: 128 rows, 16 pieces
+    {
+      const int local = wave * 16 + lr;  // half 0: 128 rows, 16 pieces; piece 1 of the wave = 8 local rows further
       const int l0 = local % RA0;
-      a0_voff[i] = ((local / RA0) * (RA0 + RA1) + (PERM ? 4 * (l0 & 15) + (l0 >> 4) : l0)) * lda + chunk;
-      b0_voff[i] = ((local / RB0) * (RB0 + RB1) + local % RB0) * ldb + chunk;
+      a0_v = ((local / RA0) * (RA0 + RA1) + (PERM ? 4 * (l0 & 15) + (l0 >> 4) : l0)) * lda + chunk;
+      b0_v = ((local / RB0) * (RB0 + RB1) + local % RB0) * ldb + chunk;
     }
-#pragma unroll
-    for (int i = 0; i < nA1; ++i) {
-      const int local = (wave * nA1 + i) * 8 + lr;  // half 1 of A: 2*RA1 rows
+    if (MA1 != 4) {
+      const int local = wave * 8 + lr;  // half 1 of A: 2*RA1 rows, one piece per wave
       const int l1 = local % RA1;
-      a1_voff[i] = ((local / RA1) * (RA0 + RA1) + RA0 + (PERM ? MA1 * (l1 & 15) + (l1 >> 4) : l1)) * lda + chunk;
+      a1_v = ((local / RA1) * (RA0 + RA1) + RA0 + (PERM ? MA1 * (l1 & 15) + (l1 >> 4) : l1)) * lda + chunk;
     }
-#pragma unroll
-    for (int i = 0; i < nB1; ++i) {
-      const int local = (wave * nB1 + i) * 8 + lr;  // half 1 of B: 4*RB1 rows
-      b1_voff[i] = ((local / RB1) * (RB0 + RB1) + RB0 + local % RB1) * ldb + chunk;
+    if (NB1 != 2) {
+      const int local = wave * 8 + lr;  // half 1 of B: 4*RB1 rows, one piece per wave
+      b1_v = ((local / RB1) * (RB0 + RB1) + RB0 + local % RB1) * ldb + chunk;
     }
   }
+  const int stepA = (PERM ? 32 : 8) * lda, stepB = 8 * ldb;  // local row + 8 -> tile row + 8 (PERM: fragment row slot + 8 = 32 rows)
+  auto dma = [&](rsrc_t rs, uint8_t* dst, int voff, int soff) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(dst), 16, voff, soff, 0, 0);
+  };
+  auto stage_a0 = [&](int soff, uint8_t* buf) __attribute__((always_inline)) {
+    dma(rsA, buf + kOffA0 + (wave * 2) * 1024, a0_v, soff);
+    dma(rsA, buf + kOffA0 + (wave * 2 + 1) * 1024, a0_v, soff + stepA);
+  };
+  auto stage_b0 = [&](int soff, uint8_t* buf) __attribute__((always_inline)) {
+    dma(rsB, buf + kOffB0 + (wave * 2) * 1024, b0_v, soff);
+    dma(rsB, buf + kOffB0 + (wave * 2 + 1) * 1024, b0_v, soff + stepB);
+  };
+  auto stage_a1 = [&](int soff, uint8_t* buf) __attribute__((always_inline)) {
+    if (MA1 == 4) {  // same row map as half 0, RA0 tile rows further
+      dma(rsA, buf + kOffA1 + (wave * 2) * 1024, a0_v, soff + RA0 * lda);
+      dma(rsA, buf + kOffA1 + (wave * 2 + 1) * 1024, a0_v, soff + RA0 * lda + stepA);
+    } else {
+      dma(rsA, buf + kOffA1 + wave * 1024, a1_v, soff);
+    }
+  };
+  auto stage_b1 = [&](int soff, uint8_t* buf) __attribute__((always_inline)) {
+    if (NB1 == 2) {
+      dma(rsB, buf + kOffB1 + (wave * 2) * 1024, b0_v, soff + RB0 * ldb);
+      dma(rsB, buf + kOffB1 + (wave * 2 + 1) * 1024, b0_v, soff + RB0 * ldb + stepB);
+    } else {
+      dma(rsB, buf + kOffB1 + wave * 1024, b1_v, soff);
+    }
+  };
 
   // pipeline cursors (wave-uniform byte offsets of the (tile, K-tile) of step s+1 / s+2, clamped to the last step)
   const int total = SK ? sk_total : my_tiles * nk;
@@ -536,17 +565,17 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   // at kernel start.  The map costs three integer divisions; evaluated at every tile switch (twice per tile, once per prefetch
   // cursor, plus once for the output offset) it held both wave groups for ~300 cycles each time with the matrix pipes idle
   // (per-phase stamps, tools/bench_kernels.py --which stamps).  Tiles beyond the 64th fall back to the scalar evaluation.
-  int tab_ra, tab_rb;
+  int tab;  // tile row index | tile column index << 16 (both < 2^15: the host checks M, N < 2^31 bytes of footprint)
   {
     int tm, tn;
     tile_mn(min(lane, max(total_tiles_hint - 1, 0)), tm, tn);
-    tab_ra = tm * TBM;
-    tab_rb = tn * TBN;
+    tab = tm | (tn << 16);
   }
   auto tile_rc = [&](int ti, int& ra, int& rb) {
     if (ti < 64) {
-      ra = __builtin_amdgcn_readlane(tab_ra, ti);
-      rb = __builtin_amdgcn_readlane(tab_rb, ti);
+      const int t = __builtin_amdgcn_readlane(tab, ti);
+      ra = (t & 0xFFFF) * TBM;
+      rb = (int)((unsigned)t >> 16) * TBN;
     } else {
       int tm, tn;
       tile_mn(ti, tm, tn);
@@ -587,12 +616,12 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   const int kb0 = SK ? sk_k0 * BK : 0;  // first step's K offset (bytes)
   stage_scales(0, SK ? sk_k0 : 0, ra_0, rb_0);
   stage_bias(0, rb_0);
-  stage_n<2>(rsA, a0_voff, oa_0 + kb0, buf0 + kOffA0, wave);
-  stage_n<2>(rsB, b0_voff, ob_0 + kb0, buf0 + kOffB0, wave);
-  stage_n<nB1>(rsB, b1_voff, ob_0 + kb0, buf0 + kOffB1, wave);
-  stage_n<nA1>(rsA, a1_voff, oa_0 + kb0, buf0 + kOffA1, wave);
-  stage_n<2>(rsA, a0_voff, oa_1 + kt_1 * BK, buf1 + kOffA0, wave);
-  stage_n<2>(rsB, b0_voff, ob_1 + kt_1 * BK, buf1 + kOffB0, wave);
+  stage_a0(oa_0 + kb0, buf0);
+  stage_b0(ob_0 + kb0, buf0);
+  stage_b1(ob_0 + kb0, buf0);
+  stage_a1(oa_0 + kb0, buf0);
+  stage_a0(oa_1 + kt_1 * BK, buf1);
+  stage_b0(ob_1 + kt_1 * BK, buf1);
   if (!SK && sk_U > 0) {
     // Start stagger (sk_U = units of 512 cycles per class, 0 = off): the CUs of an XCD start in 4 classes a few microseconds
     // apart, so their epilogue store bursts (128 KiB per CU and tile, all CUs at once = 32 MiB against ~6 TB/s of store
@@ -832,7 +861,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
     if (MODE == 1) {
       stage_scales(slot ^ 1, kt_1, ra_1, rb_1);
       stage_bias(ti_1 & 1, rb_1);
-      stage_n<nB1>(rsB, b1_voff, sb1, oth + kOffB1, wave);
+      stage_b1(sb1, oth);
       if (flag) {
         if (EPI4) epi_part(c0_t{}, c0_t{}, d_prev, bslot_prev, !ZC);
         else epi_part(c0_t{}, c2_t{}, d_prev, bslot_prev, !ZC);
@@ -867,7 +896,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
     if (MODE != 1) {
       stage_scales(slot ^ 1, kt_1, ra_1, rb_1);
       stage_bias(ti_1 & 1, rb_1);
-      stage_n<nB1>(rsB, b1_voff, sb1, oth + kOffB1, wave);
+      stage_b1(sb1, oth);
     }
     MI_WAIT_SYNC(MODE, flag, 0)
     stamp();
@@ -883,13 +912,13 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
     stamp();
     // ---- phase 1: C[0][*][1][*]
     if (MODE == 1) {
-      stage_n<nA1>(rsA, a1_voff, sa1, oth + kOffA1, wave);
+      stage_a1(sa1, oth);
       if (flag && EPI4) epi_part(c0_t{}, c1_t{}, d_prev, bslot_prev, !ZC);
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int j = 0; j < NB1; ++j) b1f[j] = read_frag(cur + kOffB1, wc * NB1 + j, lane);
-    if (MODE != 1) stage_n<nA1>(rsA, a1_voff, sa1, oth + kOffA1, wave);
+    if (MODE != 1) stage_a1(sa1, oth);
     MI_WAIT_SYNC(MODE, flag, 1)
     stamp();
 #pragma unroll
@@ -904,7 +933,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
     stamp();
     // ---- phase 2: C[1][*][1][*]
     if (MODE == 1) {
-      stage_n<2>(rsA, a0_voff, sa2, cur + kOffA0, wave);
+      stage_a0(sa2, cur);
       if (flag) {
         if (EPI4) epi_part(c1_t{}, c0_t{}, d_prev, bslot_prev, !ZC);
         else epi_part(c1_t{}, c2_t{}, d_prev, bslot_prev, !ZC);
@@ -913,7 +942,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
     }
 #pragma unroll
     for (int i = 0; i < MA1; ++i) af[i] = read_frag(cur + kOffA1, wr * MA1 + i, lane);
-    if (MODE != 1) stage_n<2>(rsA, a0_voff, sa2, cur + kOffA0, wave);
+    if (MODE != 1) stage_a0(sa2, cur);
     MI_WAIT_SYNC(MODE, flag, 2)
     stamp();
 #pragma unroll
@@ -927,7 +956,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
     MI_PHASE_END();
     stamp();
     // ---- phase 3: C[1][*][0][*]
-    stage_n<2>(rsB, b0_voff, sb2, cur + kOffB0, wave);
+    stage_b0(sb2, cur);
     if (MODE == 1) {
       if (flag && EPI4) epi_part(c1_t{}, c1_t{}, d_prev, bslot_prev, !ZC);
       __builtin_amdgcn_sched_barrier(0);
