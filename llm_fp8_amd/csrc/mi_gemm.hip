@@ -30,6 +30,7 @@
 // Replaces the cuBLASLt FP8 GEMMs behind te.Linear / LayerNormLinear / LayerNormMLP on the
 // reference path (te_llama.py:45-63,76-80; Appendix B shapes).
 #include "mi_gemm_dev.h"
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <type_traits>
@@ -417,6 +418,8 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   constexpr int nA1 = MA1 / 2, nB1 = NB1;                            // LDS-DMA pieces per wave of the second halves
   // extra LDS-DMA ops per K-tile at the head of phase 0: the bias window and, for MX, one 256-byte run of block scales per
   // wave (operand w>>2, k-block w&3) for the NEXT step; phase 3's wait retires them (see MI_WAIT_SYNC).
+  // epilogue store policy (buffer aux bits: 1 = sc0, 2 = nt, 16 = sc1); ABL 4 / 12 / 13 are the timing A/B builds (algo 17 / 25 / 26)
+  constexpr int kStoreAux = ABL == 4 ? 0 : ABL == 12 ? 2 : ABL == 13 ? 18 : 16;
   constexpr int EX = (MX ? 1 : 0) + (BIAS ? 1 : 0);
   constexpr int W = nA1 + nB1 + 4;                                   // younger ops allowed at the p3 wait (8 for 256x256)
   constexpr int NST = (4 + MA1) * 2;                                 // epilogue stores per wave and tile
@@ -638,6 +641,35 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   int as_[4] = {kUnitScale, kUnitScale, kUnitScale, kUnitScale}, b0s[2] = {kUnitScale, kUnitScale}, b1s[2] = {kUnitScale, kUnitScale};
   int as1[4] = {kUnitScale, kUnitScale, kUnitScale, kUnitScale};  // scales of the A1 half (phases 2-3)
   const int sfr = lane & 15, sfq = lane >> 4;
+  // Per-lane byte addresses of this wave's first A0 / B0 fragment in the CURRENT LDS buffer (read_frag's address math: row
+  // r = lane & 15 of the 16-row group, 16-B chunks q and 4 + q through the swizzle).  The other fragments and, with the common
+  // row map (MA1 == 4 / NB1 == 2), the second halves are immediate offsets away; the buffer toggle is one v_xor per register at
+  // the end of every K-tile, issued inside the last MFMA segment (kBufBytes = 64 KiB does not fit the 16-bit DS offset).
+  int fa_lo, fa_hi, fb_lo, fb_hi, fa1_lo = 0, fa1_hi = 0, fb1_lo = 0, fb1_hi = 0;
+  {
+    const int frow = (sfr >> 3) * 1024 + (sfr & 7) * 128;
+    const int flo = frow + ((sfq ^ swz_f(sfr)) << 4), fhi = frow + (((4 + sfq) ^ swz_f(sfr)) << 4);
+    const int l0 = (int)(size_t)LDS_PTR(lds);
+    fa_lo = l0 + kOffA0 + wr * 4 * 2048 + flo;
+    fa_hi = l0 + kOffA0 + wr * 4 * 2048 + fhi;
+    fb_lo = l0 + kOffB0 + wc * 2 * 2048 + flo;
+    fb_hi = l0 + kOffB0 + wc * 2 * 2048 + fhi;
+    if (MA1 != 4) {
+      fa1_lo = l0 + kOffA1 + wr * MA1 * 2048 + flo;
+      fa1_hi = l0 + kOffA1 + wr * MA1 * 2048 + fhi;
+    }
+    if (NB1 != 2) {
+      fb1_lo = l0 + kOffB1 + wc * NB1 * 2048 + flo;
+      fb1_hi = l0 + kOffB1 + wc * NB1 * 2048 + fhi;
+    }
+  }
+  auto frag_toggle = [&]() __attribute__((always_inline)) {
+    asm volatile("v_xor_b32 %0, 0x10000, %0\n\tv_xor_b32 %1, 0x10000, %1\n\tv_xor_b32 %2, 0x10000, %2\n\tv_xor_b32 %3, 0x10000, %3"
+                 : "+v"(fa_lo), "+v"(fa_hi), "+v"(fb_lo), "+v"(fb_hi));
+    if (MA1 != 4) asm volatile("v_xor_b32 %0, 0x10000, %0\n\tv_xor_b32 %1, 0x10000, %1" : "+v"(fa1_lo), "+v"(fa1_hi));
+    if (NB1 != 2) asm volatile("v_xor_b32 %0, 0x10000, %0\n\tv_xor_b32 %1, 0x10000, %1" : "+v"(fb1_lo), "+v"(fb1_hi));
+  };
+  static_assert(kBufBytes == 0x10000, "frag_toggle assumes 64-KiB buffers");
   int s = 0;  // current step
   // One K-tile = 4 phases; LDS-DMA issued per phase: p0 {EX, B1(step+1): nB1}, p1 {A1(step+1): nA1}, p2 {A0(step+2): 2},
   // p3 {B0(step+2): 2}; fragments read at the TOP of a phase (before its wait + barrier): p0 A0/B0, p1 B1, p2 A1.
@@ -648,30 +680,35 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   //   p1: nothing new     -> as loose as p0's successor allows            = W + EX
   //   p2: A0/B0(step+1)   -> EX + nB1 + nA1 + 2 younger                   = W + EX - 2
   //   p3: B1(step+1)      -> nA1 + 2 + 2 younger                          = W - nB1
-  // Epilogue, DISTRIBUTED (non-stream-K path): a finished tile is converted and stored in the load segments of the four phases
-  // of the NEXT tile's first K-tile (mode 1), a quarter per phase (epi_part: fragment rows [0, H) of a half in the phase whose
-  // MFMAs overwrite its first column block, rows [H, F) one phase later), always AFTER the phase's own LDS-DMA issues.  Why:
-  // vmcnt retires in order, so a wait for a load issued after a store also waits for that store's write-through acknowledge,
-  // and the CU's store path is slow (tools/probe_store.hip): with all 16 stores of a wave issued in one block the first wait
-  // behind them stalled for microseconds per tile (K sweep: 5.4 us per round of tiles, 10-13 % of the K = 3072 sites).
-  // Distributed, a store group has 4 phases to drain before a wait covers it, and the conversion VALU work runs beside the
-  // partner wave group's MFMAs.  (Two groups of 8 stores, in phases 0 and 2, were measured no better than the block epilogue.)
-  // Stores per phase: n0 = n1 = 4, n2 = n3 = MA1.  Ops allowed in flight at the four waits:
+  // Epilogue, WOVEN INTO THE MFMA SEGMENTS around a tile boundary (non-stream-K path; `mseg`): row half 0 of a tile (final after
+  // phase 1 of its last K-tile) leaves in the MFMA segments of phases 2 and 3 of that K-tile (mode 3), row half 1 in those of phases 0
+  // and 1 of the next tile's first K-tile (mode 1), whose zero-C MFMAs overwrite it in phases 2 and 3.  Stores per MFMA segment:
+  // 4 | 4 | MA1 | MA1.  vmcnt retires in order, so a wait must also allow the stores issued after the load it awaits: the load
+  // awaited at the wait of (global) phase P was issued in the load segment of phase P - 3 (p1's: P - 4, treated as P - 3, which
+  // only makes that wait stricter), so the stores of the MFMA segments of phases P - 3 .. P - 1 may stay in flight:
+  //   mode 3 (flag: always):                 p3 + 4
+  //   mode 1, flag = a previous tile exists:  p0 + 8 | p1 + 8 + MA1 | p2 + 4 + 2 MA1 | p3 + 2 MA1
+  //   mode 2, flag = behind such a K-tile:    p0 + MA1
   //   mode 0, flag = first K-tile behind a BLOCK epilogue (stream-K path, algo 46): p0-p2 + NST, p3 + 0 (awaits B1 issued after them)
-  //   mode 1, flag = a previous tile is stored in this K-tile:  + n0 | + n0+n1 | + n0+n1+n2 | + n0+n1+n2+n3
-  //           (every awaited load is older than the stores counted: p3's B1 was issued in p0 BEFORE the first store)
-  //   mode 2, flag = the K-tile behind such a mode-1 K-tile:  p0 awaits A1 issued in its p1, between the stores of n0 and n1:
-  //           + n1+n2+n3;  p1 the same;  p2 awaits B0 issued in its p3 before the stores of n3: + n3;  p3: + 0
-  // MX (no registers for the parked block): the halves leave whole in phases 0 and 2: n0 = 8, n1 = 0, n2 = 2 MA1, n3 = 0.
+  // A store is thus first covered by a wait 4 phases after its issue.
 #define MI_WAIT_SYNC(MODE_, flag, PH)                                                                              \
   {                                                                                                                \
     constexpr int kAllow = (PH) == 0 ? W + EX - nA1 : (PH) == 1 ? W + EX : (PH) == 2 ? W + EX - 2 : W - nB1;       \
-    constexpr int kS0 = MX ? 8 : 4, kS1 = MX ? 0 : 4, kS2 = MX ? 2 * MA1 : MA1, kS3 = MX ? 0 : MA1; /* stores per phase */ \
-    constexpr int kX = (MODE_) == 0 ? ((PH) != 3 ? NST : 0)                                                        \
-                     : (MODE_) == 1 ? ((PH) == 0 ? kS0 : (PH) == 1 ? kS0 + kS1 : (PH) == 2 ? kS0 + kS1 + kS2 : kS0 + kS1 + kS2 + kS3) \
-                                    : ((PH) <= 1 ? kS1 + kS2 + kS3 : (PH) == 2 ? kS3 : 0);                         \
-    if ((flag) && kX != 0) wait_vmcnt<kAllow + kX>();                                                              \
-    else wait_vmcnt<kAllow>();                                                                                     \
+    /* stores that may stay in flight: woven = MFMA segments P-3..P-1, load-segment placement = load segments P-3..P */ \
+    constexpr int kXw = (MODE_) == 1 ? ((PH) == 0 ? 8 : (PH) == 1 ? 8 + MA1 : (PH) == 2 ? 4 + 2 * MA1 : 2 * MA1)   \
+                      : (MODE_) == 2 ? ((PH) == 0 ? MA1 : 0)                                                       \
+                      : (MODE_) == 3 ? ((PH) == 3 ? 4 : 0)                                                         \
+                                     : ((PH) == 0 ? MA1 : (PH) == 3 ? 4 : 0); /* mode 4 = modes 2 and 3 in one */  \
+    constexpr int kXl = (MODE_) == 1 ? ((PH) == 0 ? 8 + MA1 : (PH) == 1 ? 8 + 2 * MA1 : (PH) == 2 ? 4 + 2 * MA1 : 2 * MA1) \
+                      : (MODE_) == 2 ? ((PH) == 0 ? MA1 : 0)                                                       \
+                      : (MODE_) == 3 ? ((PH) == 2 ? 4 : (PH) == 3 ? 8 : 0)                                         \
+                                     : ((PH) == 0 ? MA1 : (PH) == 2 ? 4 : (PH) == 3 ? 8 : 0);                      \
+    constexpr int kX = (MODE_) == 0 ? ((PH) != 3 ? NST : 0) : kWoven ? kXw : kXl;                                  \
+    constexpr bool kOwn = (MODE_) >= 3 && (PH) >= 2; /* this tile's own half 0: unconditional */                   \
+    if (kX != 0 && ((flag) || kOwn)) {                                                                             \
+      if ((MODE_) == 4 && (PH) == 0 && !(flag)) wait_vmcnt<kAllow>();                                              \
+      else wait_vmcnt<kAllow + kX>();                                                                              \
+    } else wait_vmcnt<kAllow>();                                                                                   \
   }                                                                                                                \
   __builtin_amdgcn_s_barrier();                                                                                    \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
@@ -704,174 +741,223 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   // 8 + (m & 7); lanes m >= 8 carry the second 32-column block of those rows
   const int d_voff_line = ((wr * (RA0 + RA1) + (PERM ? 4 : 1) * (fr & 7)) * ldd + wc * (RB0 + RB1) + (fr >> 3) * RB0 + ecol) * 2;
   const int d_voff_line1 = (PERM && MA1 != 4) ? ((wr * (RA0 + RA1) + MA1 * (fr & 7)) * ldd + wc * (RB0 + RB1) + (fr >> 3) * RB0 + ecol) * 2 : d_voff_line;
-  // convert + store the accumulators of row half a (both column blocks) of the tile whose output starts at byte d_tile; bias slot bslot.
-  // A fragment pair (a, i, b) gives, after the permlane16 swap, 16 rows x 64 B per store instruction: half-line segments,
-  // which one CU stores at 33 GB/s whatever the cache policy, against 72-118 GB/s for whole 128-B lines
-  // (tools/probe_store.hip).  With NB1 == 2 the two column blocks of a fragment row are therefore exchanged between lanes m and
-  // m ^ 8 (DPP row_ror:8): store 1 = rows 0-7 x 128 B, store 2 = rows 8-15 x 128 B.
-  // PART 0 / 1 = first / second phase of the half (phases 0, 1 for half 0; 2, 3 for half 1); PART 2 = the whole half at once.
-  // The column block that the first phase's MFMAs are about to overwrite (block 0 for half 0, block 1 for half 1) is packed
-  // for the second group of fragment rows and parked in `held` (8 registers) until the second phase, where it meets the other
-  // column block of the same rows: every phase issues the same number of stores (4 | 4 | MA1 | MA1), all whole-line.
-  constexpr bool EPI4 = !MX;  // MX: no registers left for `held` -> the halves leave whole, in phases 0 and 2
-  v4i held[2];
-  auto epi_part = [&](auto a_c, auto part_c, int d_tile, int bslot, bool zero) __attribute__((always_inline)) {
-    constexpr int a = decltype(a_c)::value, PART = decltype(part_c)::value;
-    constexpr int F = a == 0 ? 4 : MA1, H = F / 2;  // fragment rows of the half; rows [0, H) leave in part 0, [H, F) in part 1
-    constexpr int bf = a == 0 ? 0 : 1;              // the column block overwritten first
-    float bv[2][2][4];
+  // Epilogue of one FRAGMENT ROW (a, i) = 16 tile rows x this wave's columns, in four sub-steps that the K-tiles around a tile
+  // boundary weave between their MFMAs (see `mseg`): 0 / 1 = scale (+ bias), convert and gather column block 0 / 1 into
+  // 16 B per lane (8 contiguous columns from ecol: two MFMA tiles, permlane16 swap), 2 = exchange for whole lines, 3 = stores.
+  // A fragment pair gives 16 rows x 64 B per store instruction: half-line segments, which one CU stores at 33 GB/s whatever
+  // the cache policy, against 72-118 GB/s for whole 128-B lines (tools/probe_store.hip).  With NB1 == 2 the two column blocks
+  // of a fragment row are therefore exchanged between lanes m and m ^ 8 (DPP row_ror:8, bank-masked): store 1 = rows 0-7 x 128 B,
+  // store 2 = rows 8-15 x 128 B.
+  typedef unsigned int v2u_ __attribute__((ext_vector_type(2)));
+  v2u_ bias_w[2][2];  // BIAS: this wave's bias window (bf16 x 4 per lane and MFMA tile), read once per segment
+  v4i e_o0, e_o1;     // sub-step state of the row in flight
+  auto epi_begin = [&](int bslot) __attribute__((always_inline)) {
     if (BIAS) {
-      // This wave's own LDS-DMA data, landed long ago (covered by the vmcnt waits of the previous tile's K-tiles), so no wait is
+      // This wave's own LDS-DMA data, landed long ago (covered by the vmcnt waits of the previous K-tiles), so no vmcnt wait is
       // needed -- but hipcc puts `s_waitcnt vmcnt(0)` in front of a C++ read of LDS bytes that a dword LDS-DMA may have written
       // (it cannot see the counted waits in the inline asm), which drained the whole prefetch pipeline at every use.  The reads
-      // are therefore inline asm too.
+      // are therefore inline asm too; epi_step waits for them (lgkmcnt) before the first use.
       const unsigned bp = (unsigned)(size_t)LDS_PTR(bbuf + (bslot * 8 + wave) * 256 + fq * 8);
-      typedef unsigned int v2u_ __attribute__((ext_vector_type(2)));
-      v2u_ w[2][2];
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int j = 0; j < (b == 0 ? 2 : NB1); ++j)
-          asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(w[b][j]) : "v"(bp), "n"((b * RB0 + j * 16) * 2));
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int j = 0; j < (b == 0 ? 2 : NB1); ++j) {
-          bv[b][j][0] = __uint_as_float(w[b][j].x << 16);
-          bv[b][j][1] = __uint_as_float(w[b][j].x & 0xFFFF0000u);
-          bv[b][j][2] = __uint_as_float(w[b][j].y << 16);
-          bv[b][j][3] = __uint_as_float(w[b][j].y & 0xFFFF0000u);
-        }
+          asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(bias_w[b][j]) : "v"(bp), "n"((b * RB0 + j * 16) * 2));
     }
-    auto zero_blk = [&](int i, int b) __attribute__((always_inline)) {
+  };
+  auto epi_step = [&](auto a_c, int i, int st, int d_tile, bool zero, bool first) __attribute__((always_inline)) {
+    constexpr int a = decltype(a_c)::value;
+    constexpr int F = a == 0 ? 4 : MA1;
+    auto biased = [&](v4f v, int b, int j) __attribute__((always_inline)) -> v4f {
+      if (BIAS) {
+        v[0] += __uint_as_float(bias_w[b][j].x << 16);
+        v[1] += __uint_as_float(bias_w[b][j].x & 0xFFFF0000u);
+        v[2] += __uint_as_float(bias_w[b][j].y << 16);
+        v[3] += __uint_as_float(bias_w[b][j].y & 0xFFFF0000u);
+      }
+      return v;
+    };
+    auto pack_blk = [&](int b) __attribute__((always_inline)) -> v4i {
+      v4i r;
+      if (b == 1 && NB1 == 1) {  // single-tile block of the 192-column shapes: 4 columns in .x/.y
+        const v4f v0 = biased(acc[a][i][1][0] * alpha, 1, 0);
+        r = (v4i){(int)pack_bf16x2(v0[0], v0[1]), (int)pack_bf16x2(v0[2], v0[3]), 0, 0};
+      } else {
+        const v4f v0 = biased(acc[a][i][b][0] * alpha, b, 0), v1 = biased(acc[a][i][b][1] * alpha, b, 1);
+        u32 p0x = pack_bf16x2(v0[0], v0[1]), p0y = pack_bf16x2(v0[2], v0[3]);
+        u32 p1x = pack_bf16x2(v1[0], v1[1]), p1y = pack_bf16x2(v1[2], v1[3]);
+        auto sx = __builtin_amdgcn_permlane16_swap(p0x, p1x, false, false);
+        auto sy = __builtin_amdgcn_permlane16_swap(p0y, p1y, false, false);
+        r = (v4i){(int)sx[0], (int)sy[0], (int)sx[1], (int)sy[1]};
+      }
       if (zero) {
 #pragma unroll
         for (int j = 0; j < (b == 0 ? 2 : NB1); ++j) acc[a][i][b][j] = (v4f){0.f, 0.f, 0.f, 0.f};
       }
+      return r;
     };
-    // 16 B per lane of column block b, row (a, i, fr): 8 contiguous columns from ecol (two MFMA tiles, permlane16 swap), or for
-    // the single-tile block of the 192-column shapes (NB1 == 1, b == 1) 4 columns in .x/.y
-    auto pack_blk = [&](int i, int b) __attribute__((always_inline)) -> v4i {
-      if (b == 1 && NB1 == 1) {
-        v4f v0 = acc[a][i][1][0] * alpha;
-        if (BIAS) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v0[e] += bv[1][0][e];
-        }
-        return (v4i){(int)pack_bf16x2(v0[0], v0[1]), (int)pack_bf16x2(v0[2], v0[3]), 0, 0};
+    constexpr bool LINES = NB1 == 2 && ABL != 11;
+    if (st == 0) {
+      if (BIAS && first) {  // the window reads of epi_begin: tie the registers to the wait so that no use is scheduled above it
+        if (NB1 == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bias_w[0][0]), "+v"(bias_w[0][1]), "+v"(bias_w[1][0]), "+v"(bias_w[1][1])::"memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bias_w[0][0]), "+v"(bias_w[0][1]), "+v"(bias_w[1][0])::"memory");
       }
-      v4f v0 = acc[a][i][b][0] * alpha, v1 = acc[a][i][b][1] * alpha;
-      if (BIAS) {
+      e_o0 = pack_blk(0);
+    } else if (st == 1) {
+      e_o1 = pack_blk(1);
+    } else if (st == 2) {
+      if (LINES) {
+        // x = block 0 of rows m < 8 | block 1 of rows m - 8;  y = block 0 of rows m + 8 | block 1 of rows m >= 8: lane m takes
+        // from lane m ^ 8 (row_ror:8) in the banks (groups of 4 lanes of a 16-lane row) where it holds the other block
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v0[e] += bv[b][0][e];
-          v1[e] += bv[b][1][e];
+          const int keep = e_o1[e];
+          e_o1[e] = __builtin_amdgcn_update_dpp(e_o1[e], e_o0[e], 0x128, 0xF, 0x3, false);  // banks 0-1 (m < 8) <- block 0 of row m + 8
+          e_o0[e] = __builtin_amdgcn_update_dpp(e_o0[e], keep, 0x128, 0xF, 0xC, false);     // banks 2-3 (m >= 8) <- block 1 of row m - 8
         }
       }
-      u32 p0x = pack_bf16x2(v0[0], v0[1]), p0y = pack_bf16x2(v0[2], v0[3]);
-      u32 p1x = pack_bf16x2(v1[0], v1[1]), p1y = pack_bf16x2(v1[2], v1[3]);
-      auto sx = __builtin_amdgcn_permlane16_swap(p0x, p1x, false, false);
-      auto sy = __builtin_amdgcn_permlane16_swap(p0y, p1y, false, false);
-      return (v4i){(int)sx[0], (int)sy[0], (int)sx[1], (int)sy[1]};
-    };
-    // hipcc (ROCm 7.2) lets the next VALU overwrite the data registers of a 16-byte store (SGPR-offset form) with no wait
-    // state: lanes 12-15 of every 16-lane row then stored the NEXT block's unconverted fp32 (seen on MI355X).  Every store is
-    // followed by `s_nop 1` that keeps its registers live across the required wait states.
-    // aux 16 = sc1: write-through, the line is not kept in this XCD's L2.  A tile's 128 KiB of output per CU (4 MiB per XCD =
-    // its whole L2) would otherwise evict the A/B panels the next tile streams (measured -5..6 % kernel time at K = 2048-4096).
-    auto store_row = [&](int i, const v4i& o0, const v4i& o1) __attribute__((always_inline)) {  // o0 / o1 = column block 0 / 1
+    } else {
+      // hipcc (ROCm 7.2) lets the next VALU overwrite the data registers of a 16-byte store (SGPR-offset form) with no wait
+      // state: lanes 12-15 of every 16-lane row then stored the NEXT block's unconverted fp32 (seen on MI355X).  Every store is
+      // followed by `s_nop 1` that keeps its registers live across the required wait states.
+      // aux 16 = sc1: write-through, the line is not kept in this XCD's L2.  A tile's 128 KiB of output per CU (4 MiB per XCD =
+      // its whole L2) would otherwise evict the A/B panels the next tile streams (measured -5..6 % kernel time at K = 2048-4096).
       const int rowoff = d_tile + ((a * RA0 + (PERM ? i : i * 16)) * ldd) * 2;
       if (ABL == 1) {
-        asm volatile("" ::"v"(o0), "v"(o1));
-      } else if (NB1 == 2 && ABL != 11) {
-        const bool lo = fr < 8;
-        v4i x, y;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int t = lo ? o1[e] : o0[e];                                          // what lane m ^ 8 needs
-          const int r = __builtin_amdgcn_update_dpp(0, t, 0x128, 0xF, 0xF, false);  // row_ror:8 = lane m ^ 8 of the 16-lane row
-          x[e] = lo ? o0[e] : r;
-          y[e] = lo ? r : o1[e];
-        }
+        asm volatile("" ::"v"(e_o0), "v"(e_o1));
+      } else if (LINES) {
         const int dvo = a == 0 ? d_voff_line : d_voff_line1;
         constexpr int kRow8 = 8 * (PERM ? F : 1);
-        __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)x, rsD, dvo, rowoff, ABL == 4 ? 0 : 16);
-        asm volatile("s_nop 1" ::"v"(x) : "memory");
-        __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)y, rsD, dvo, rowoff + kRow8 * ldd * 2, ABL == 4 ? 0 : 16);
-        asm volatile("s_nop 1" ::"v"(y) : "memory");
+        __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)e_o0, rsD, dvo, rowoff, kStoreAux);
+        asm volatile("s_nop 1" ::"v"(e_o0) : "memory");
+        __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)e_o1, rsD, dvo, rowoff + kRow8 * ldd * 2, kStoreAux);
+        asm volatile("s_nop 1" ::"v"(e_o1) : "memory");
       } else {  // half-line stores: 192-column shapes (NB1 == 1: 64 B + 32 B per row), and ABL == 11 (A/B baseline)
         const int dvo = a == 0 ? d_voff : d_voff1;
-        __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)o0, rsD, dvo + ecol * 2, rowoff, ABL == 4 ? 0 : 16);
-        asm volatile("s_nop 1" ::"v"(o0) : "memory");
+        __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)e_o0, rsD, dvo + ecol * 2, rowoff, kStoreAux);
+        asm volatile("s_nop 1" ::"v"(e_o0) : "memory");
         if (NB1 == 2) {
-          __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)o1, rsD, dvo + ecol * 2, rowoff + RB0 * 2, ABL == 4 ? 0 : 16);
+          __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)e_o1, rsD, dvo + ecol * 2, rowoff + RB0 * 2, kStoreAux);
         } else {
-          typedef unsigned int v2u __attribute__((ext_vector_type(2)));
-          const v2u o2 = {(unsigned)o1[0], (unsigned)o1[1]};
+          const v2u_ o2 = {(unsigned)e_o1[0], (unsigned)e_o1[1]};
           __builtin_amdgcn_raw_buffer_store_b64(o2, rsD, dvo + fq * 8, rowoff + RB0 * 2, 16);
         }
-        asm volatile("s_nop 1" ::"v"(o1) : "memory");
-      }
-    };
-#pragma unroll
-    for (int i = 0; i < F; ++i) {
-      const bool first_rows = i < H;
-      if (PART == 2 || (PART == 0 && first_rows)) {  // both column blocks now
-        const v4i o0 = pack_blk(i, 0), o1 = pack_blk(i, 1);
-        store_row(i, o0, o1);
-        zero_blk(i, 0);
-        zero_blk(i, 1);
-      } else if (PART == 0) {  // park the block that is about to be overwritten
-        held[i - H] = pack_blk(i, bf);
-        zero_blk(i, bf);
-      } else if (!first_rows) {  // PART == 1: the parked block meets the other one
-        const v4i oo = pack_blk(i, 1 - bf);
-        if (bf == 0) store_row(i, held[i - H], oo);
-        else store_row(i, oo, held[i - H]);
-        zero_blk(i, 1 - bf);
+        asm volatile("s_nop 1" ::"v"(e_o1) : "memory");
       }
     }
   };
   using c0_t = std::integral_constant<int, 0>;
   using c1_t = std::integral_constant<int, 1>;
   using c2_t = std::integral_constant<int, 2>;
-  auto epilogue_block = [&](int ti, bool zero) __attribute__((always_inline)) {  // both halves at once (last tile of a workgroup; stream-K path)
+  using c3_t = std::integral_constant<int, 3>;
+  using c4_t = std::integral_constant<int, 4>;
+  using c8_t = std::integral_constant<int, 8>;
+  // the fragment rows [r0, r0 + nr) of half a, back to back (after the tile walk; stream-K / block-epilogue path)
+  auto epi_rows = [&](auto a_c, int r0, int nr, int d_tile, int bslot, bool zero) __attribute__((always_inline)) {
+    epi_begin(bslot);
+#pragma unroll
+    for (int r = 0; r < nr; ++r)
+#pragma unroll
+      for (int st = 0; st < 4; ++st) epi_step(a_c, r0 + r, st, d_tile, zero, r == 0);
+  };
+  auto epilogue_block = [&](int ti, bool zero) __attribute__((always_inline)) {  // both halves at once (stream-K / block-epilogue path)
     const int d_tile = tile_d_off(ti);
-    epi_part(c0_t{}, c2_t{}, d_tile, ti & 1, zero);
-    epi_part(c1_t{}, c2_t{}, d_tile, ti & 1, zero);
+    epi_rows(c0_t{}, 0, 4, d_tile, ti & 1, zero);
+    epi_rows(c1_t{}, 0, MA1, d_tile, ti & 1, zero);
+  };
+  // An MFMA segment of NI x NJ MFMAs (mf(i, j)) with, when `on`, the epilogue of NR fragment rows [r0, r0 + NR) of half a woven
+  // in: after MFMA k the sub-steps [4 NR k / NM, 4 NR (k + 1) / NM).  The conversion VALU work then runs in the shadow of the
+  // wave's OWN MFMAs (the matrix pipe is busy 32 cycles per MFMA, the wave's issue port 4-8), and the stores leave at the rate
+  // the CU's store path takes them.  In the load segments -- where the quadrants were converted before -- every cycle of
+  // epilogue work held the partner wave group at its barrier with the matrix pipe idle, and the two groups' shares came one
+  // after the other: per-phase stamps showed ~8.7k cycles per tile boundary, 16 % of a K = 3072 tile.
+  auto mseg = [&](auto ni_c, auto nj_c, auto mf, auto a_c, auto nr_c, int r0, bool on, int d_tile, int bslot, bool zero)
+                  __attribute__((always_inline)) {
+    constexpr int NI = decltype(ni_c)::value, NJ = decltype(nj_c)::value, NM = NI * NJ;
+    constexpr int NR = decltype(nr_c)::value, NE = 4 * NR, MAXU = NR == 0 ? 0 : (NE + NM - 1) / NM;
+    if (NR > 0 && on) epi_begin(bslot);
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        mf(i, j);
+        if (NR > 0) {
+          const int k = i * NJ + j;
+          if (on) {
+#pragma unroll
+            for (int u = 0; u < MAXU; ++u) {
+              const int e = k * NE / NM + u;
+              if (e < (k + 1) * NE / NM) epi_step(a_c, r0 + e / 4, e % 4, d_tile, zero, e < 4);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
   };
 
-  // mode 0: plain K-tile (flag: behind a block epilogue); mode 1: first K-tile of a tile -- zero-C MFMAs, and when `flag` the
-  // quadrants of the previous tile (output offset d_prev, bias slot bslot_prev) leave in its load segments; mode 2: the K-tile
-  // behind a mode-1 K-tile (flag: that one carried stores).
-  auto ktile = [&](auto mode_c, uint8_t* cur, uint8_t* oth, bool flag, int slot, int d_prev, int bslot_prev) {
+  // The same rows in a LOAD segment instead (after the segment's own LDS-DMA issues, before its wait): the default placement.
+  // Measured (same-process A/B, 3B decoder shapes) the woven form is 1.8 % SLOWER: a wave whose store cannot issue (the CU's store
+  // path takes 22 cycles per 1-KiB store, and 4 waves store at once) also cannot issue its next MFMA, so the matrix pipe idles
+  // either way, and in a load segment the partner group's MFMAs at least run undisturbed.  kWoven (ABL 14, algo 27) keeps the
+  // woven form as a timing build.
+  constexpr bool kWoven = ABL == 14;
+  auto lseg_epi = [&](auto a_c, auto nr_c, int r0, bool on, int d_tile, int bslot, bool zero) __attribute__((always_inline)) {
+    constexpr int NR = decltype(nr_c)::value;
+    if (NR > 0 && !kWoven) {
+      if (on) epi_rows(a_c, r0, NR, d_tile, bslot, zero);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // mode 0: plain K-tile (flag: behind a block epilogue); mode 1: first K-tile of a tile -- zero-C MFMAs, and when `flag` row half 1
+  // of the PREVIOUS tile (output offset d_tile, bias slot bslot) leaves woven into the MFMA segments of phases 0 and 1; mode 2: the
+  // K-tile behind a mode-1 K-tile (flag: that one carried stores); mode 3: last K-tile of a tile -- row half 0 of THIS tile, final
+  // after phase 1, leaves in the MFMA segments of phases 2 and 3; mode 4 (K = 256: two K-tiles per tile) = modes 2 and 3 in one.
+  auto ktile = [&](auto mode_c, uint8_t* cur, uint8_t* oth, bool flag, int slot, int d_tile, int bslot) {
     constexpr int MODE = decltype(mode_c)::value;
-    // (zero-C MFMAs in the first K-tile were tried: the allocator then stops accumulating in place, spills the fresh quadrants and
-    // reloads them behind `s_waitcnt vmcnt(0)`; the quadrants are zeroed by v_mov right after their stores instead)
+    // (zero-C MFMAs through the builtin were tried: the allocator then stops accumulating in place, spills the fresh quadrants and
+    // reloads them behind `s_waitcnt vmcnt(0)`; mfma_ba_zero ties the accumulator in inline asm.  MX has no unit-scale form: its
+    // quadrants are zeroed by v_mov as they are converted.)
     constexpr bool ZC = MODE == 1 && !MX;  // first K-tile of a tile: accumulate onto zero (mfma_ba_zero), no v_mov zeroing
+    using nr01_t = std::integral_constant<int, (MODE == 1 ? MA1 / 2 : 0)>;  // fragment rows leaving in phases 0, 1 (half 1, previous tile)
+    using nr23_t = std::integral_constant<int, (MODE >= 3 ? 2 : 0)>;        // ... in phases 2, 3 (half 0, this tile)
+    using wv01_t = std::integral_constant<int, (kWoven ? nr01_t::value : 0)>;  // ... of them woven into the MFMA segment
+    using wv23_t = std::integral_constant<int, (kWoven ? nr23_t::value : 0)>;
+    using ma1_t = std::integral_constant<int, MA1>;
+    using nb1_t = std::integral_constant<int, NB1>;
     const uint8_t* sc = sbuf + slot * kSSlot + sfq * kSK + sfr;  // A scales: + tile row of the fragment
     const uint8_t* scb = sc + kSOp;                              // B scales
     const int sa1 = oa_1 + kt_1 * BK, sb1 = ob_1 + kt_1 * BK;
     const int sa2 = oa_2 + kt_2 * BK, sb2 = ob_2 + kt_2 * BK;
+    // Fragment reads: explicit per-lane bases (fa_* / fb_*, see their definition) + immediate offsets -- no address VALU in the
+    // load segments (8 v_add per K-tile there cost 2 %: every VALU instruction delays the segment's LDS-DMA issue and barrier)
+    // and no compiler-hoisted base per (operand half, buffer) (ten VGPRs, some spilled and reloaded behind `s_waitcnt vmcnt(0)`).
+    auto frag2 = [&](int lo, int hi, int off) __attribute__((always_inline)) -> v8i {
+      const v4i l = *reinterpret_cast<const __attribute__((address_space(3))) v4i*>((size_t)(unsigned)(lo + off));
+      const v4i h = *reinterpret_cast<const __attribute__((address_space(3))) v4i*>((size_t)(unsigned)(hi + off));
+      return (v8i){l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
+    };
+    auto frag = [&](int half_off, int, int g) __attribute__((always_inline)) -> v8i {
+      if (half_off == kOffA0) return frag2(fa_lo, fa_hi, g * 2048);
+      if (half_off == kOffB0) return frag2(fb_lo, fb_hi, g * 2048);
+      if (half_off == kOffA1) return MA1 == 4 ? frag2(fa_lo, fa_hi, kHalfBytes + g * 2048) : frag2(fa1_lo, fa1_hi, g * 2048);
+      return NB1 == 2 ? frag2(fb_lo, fb_hi, kHalfBytes + g * 2048) : frag2(fb1_lo, fb1_hi, g * 2048);
+    };
     // ---- phase 0: C[0][*][0][*]
-    // mode 1: the LDS-DMA issues and the previous tile's quadrant come FIRST, the fragment reads after them: the fragments are
-    // then not live across the conversion (the kernel sits at the 256-VGPR limit), at the price of their LDS latency once per tile
-    if (MODE == 1) {
+    // A load segment that carries epilogue rows issues its LDS-DMA first, then the rows, and reads its fragments LAST: the
+    // fragments are then not live across the conversion (the 256x256 variants sit at the 256-VGPR limit), at the price of their
+    // LDS latency once per such segment.
+    constexpr bool kE01 = !kWoven && nr01_t::value > 0, kE23 = !kWoven && nr23_t::value > 0;
+    if (kE01) {
       stage_scales(slot ^ 1, kt_1, ra_1, rb_1);
       stage_bias(ti_1 & 1, rb_1);
       stage_b1(sb1, oth);
-      if (flag) {
-        if (EPI4) epi_part(c0_t{}, c0_t{}, d_prev, bslot_prev, !ZC);
-        else epi_part(c0_t{}, c2_t{}, d_prev, bslot_prev, !ZC);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      lseg_epi(c1_t{}, nr01_t{}, 0, flag, d_tile, bslot, MX);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) b0f[j] = read_frag(cur + kOffB0, wc * 2 + j, lane);
+    for (int j = 0; j < 2; ++j) b0f[j] = frag(kOffB0, wc * 2, j);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = read_frag(cur + kOffA0, wr * 4 + i, lane);
+    for (int i = 0; i < 4; ++i) af[i] = frag(kOffA0, wr * 4, i);
     if (MX && ABL != 5) {  // every scale of this K-tile up front: phases 1-3 then start on their fragment reads alone
 #pragma unroll
       for (int j = 0; j < 2; ++j) b0s[j] = scb[wc * (RB0 + RB1) + j * 16];
@@ -893,83 +979,64 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
         }
       }
     }
-    if (MODE != 1) {
+    if (!kE01) {
       stage_scales(slot ^ 1, kt_1, ra_1, rb_1);
       stage_bias(ti_1 & 1, rb_1);
       stage_b1(sb1, oth);
     }
     MI_WAIT_SYNC(MODE, flag, 0)
     stamp();
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (ZC) mfma_ba_zero<FA, FB>(af[i], b0f[j], acc[0][i][0][j], b0s[j]);
-        else acc[0][i][0][j] = mfma_sel(i, af[i], b0f[j], acc[0][i][0][j], as_, b0s[j]);
-      }
+    mseg(c4_t{}, c2_t{}, [&](int i, int j) __attribute__((always_inline)) {
+      if (ZC) mfma_ba_zero<FA, FB>(af[i], b0f[j], acc[0][i][0][j], b0s[j]);
+      else acc[0][i][0][j] = mfma_sel(i, af[i], b0f[j], acc[0][i][0][j], as_, b0s[j]);
+    }, c1_t{}, wv01_t{}, 0, flag, d_tile, bslot, MX);
     MI_PIN(4, 2, acc[0][i][0][j])
     MI_PHASE_END();
     stamp();
     // ---- phase 1: C[0][*][1][*]
-    if (MODE == 1) {
+    if (kE01) {
       stage_a1(sa1, oth);
-      if (flag && EPI4) epi_part(c0_t{}, c1_t{}, d_prev, bslot_prev, !ZC);
-      __builtin_amdgcn_sched_barrier(0);
+      lseg_epi(c1_t{}, nr01_t{}, MA1 / 2, flag, d_tile, bslot, MX);
     }
 #pragma unroll
-    for (int j = 0; j < NB1; ++j) b1f[j] = read_frag(cur + kOffB1, wc * NB1 + j, lane);
-    if (MODE != 1) stage_a1(sa1, oth);
+    for (int j = 0; j < NB1; ++j) b1f[j] = frag(kOffB1, wc * NB1, j);
+    if (!kE01) stage_a1(sa1, oth);
     MI_WAIT_SYNC(MODE, flag, 1)
     stamp();
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < NB1; ++j) {
-        if (ZC) mfma_ba_zero<FA, FB>(af[i], b1f[j], acc[0][i][1][j], b1s[j]);
-        else acc[0][i][1][j] = mfma_sel(i, af[i], b1f[j], acc[0][i][1][j], as_, b1s[j]);
-      }
+    mseg(c4_t{}, nb1_t{}, [&](int i, int j) __attribute__((always_inline)) {
+      if (ZC) mfma_ba_zero<FA, FB>(af[i], b1f[j], acc[0][i][1][j], b1s[j]);
+      else acc[0][i][1][j] = mfma_sel(i, af[i], b1f[j], acc[0][i][1][j], as_, b1s[j]);
+    }, c1_t{}, wv01_t{}, MA1 / 2, flag, d_tile, bslot, MX);
     MI_PIN(4, NB1, acc[0][i][1][j])
     MI_PHASE_END();
     stamp();
     // ---- phase 2: C[1][*][1][*]
-    if (MODE == 1) {
+    if (kE23) {
       stage_a0(sa2, cur);
-      if (flag) {
-        if (EPI4) epi_part(c1_t{}, c0_t{}, d_prev, bslot_prev, !ZC);
-        else epi_part(c1_t{}, c2_t{}, d_prev, bslot_prev, !ZC);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      lseg_epi(c0_t{}, nr23_t{}, 0, true, d_tile, bslot, MX);
     }
 #pragma unroll
-    for (int i = 0; i < MA1; ++i) af[i] = read_frag(cur + kOffA1, wr * MA1 + i, lane);
-    if (MODE != 1) stage_a0(sa2, cur);
+    for (int i = 0; i < MA1; ++i) af[i] = frag(kOffA1, wr * MA1, i);
+    if (!kE23) stage_a0(sa2, cur);
     MI_WAIT_SYNC(MODE, flag, 2)
     stamp();
-#pragma unroll
-    for (int i = 0; i < MA1; ++i)
-#pragma unroll
-      for (int j = 0; j < NB1; ++j) {
-        if (ZC) mfma_ba_zero<FA, FB>(af[i], b1f[j], acc[1][i][1][j], b1s[j]);
-        else acc[1][i][1][j] = mfma_sel(i, af[i], b1f[j], acc[1][i][1][j], as1, b1s[j]);
-      }
+    mseg(ma1_t{}, nb1_t{}, [&](int i, int j) __attribute__((always_inline)) {
+      if (ZC) mfma_ba_zero<FA, FB>(af[i], b1f[j], acc[1][i][1][j], b1s[j]);
+      else acc[1][i][1][j] = mfma_sel(i, af[i], b1f[j], acc[1][i][1][j], as1, b1s[j]);
+    }, c0_t{}, wv23_t{}, 0, true, d_tile, bslot, MX);
     MI_PIN(MA1, NB1, acc[1][i][1][j])
     MI_PHASE_END();
     stamp();
     // ---- phase 3: C[1][*][0][*]
     stage_b0(sb2, cur);
-    if (MODE == 1) {
-      if (flag && EPI4) epi_part(c1_t{}, c1_t{}, d_prev, bslot_prev, !ZC);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    lseg_epi(c0_t{}, nr23_t{}, 2, true, d_tile, bslot, MX);
     MI_WAIT_SYNC(MODE, flag, 3)
     stamp();
-#pragma unroll
-    for (int i = 0; i < MA1; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (ZC) mfma_ba_zero<FA, FB>(af[i], b0f[j], acc[1][i][0][j], b0s[j]);
-        else acc[1][i][0][j] = mfma_sel(i, af[i], b0f[j], acc[1][i][0][j], as1, b0s[j]);
-      }
+    mseg(ma1_t{}, c2_t{}, [&](int i, int j) __attribute__((always_inline)) {
+      if (ZC) mfma_ba_zero<FA, FB>(af[i], b0f[j], acc[1][i][0][j], b0s[j]);
+      else acc[1][i][0][j] = mfma_sel(i, af[i], b0f[j], acc[1][i][0][j], as1, b0s[j]);
+    }, c0_t{}, wv23_t{}, 2, true, d_tile, bslot, MX);
+    frag_toggle();
     MI_PIN(MA1, 2, acc[1][i][0][j])
     MI_PHASE_END();
     stamp();
@@ -1052,19 +1119,31 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
     }
   } else {
     int d_prev = 0;
-    for (int ti = 0; ti < my_tiles; ++ti) {
-      const bool have_prev = ti > 0;
-      ktile(c1_t{}, buf0, buf1, have_prev, 0, d_prev, (ti - 1) & 1);
-      ktile(c2_t{}, buf1, buf0, have_prev, 1, 0, 0);
-      for (int pair = 1; pair < nk / 2; ++pair) {
-        ktile(c0_t{}, buf0, buf1, false, 0, 0, 0);
-        ktile(c0_t{}, buf1, buf0, false, 1, 0, 0);
+    using c4m_t = std::integral_constant<int, 4>;
+    if (nk == 2) {
+      for (int ti = 0; ti < my_tiles; ++ti) {
+        const bool have_prev = ti > 0;
+        ktile(c1_t{}, buf0, buf1, have_prev, 0, d_prev, (ti - 1) & 1);
+        d_prev = tile_d_off(ti);
+        ktile(c4m_t{}, buf1, buf0, have_prev, 1, d_prev, ti & 1);
       }
-      d_prev = tile_d_off(ti);
+    } else {
+      for (int ti = 0; ti < my_tiles; ++ti) {
+        const bool have_prev = ti > 0;
+        ktile(c1_t{}, buf0, buf1, have_prev, 0, d_prev, (ti - 1) & 1);
+        ktile(c2_t{}, buf1, buf0, have_prev, 1, 0, 0);
+        for (int pair = 2; pair < nk / 2; ++pair) {
+          ktile(c0_t{}, buf0, buf1, false, 0, 0, 0);
+          ktile(c0_t{}, buf1, buf0, false, 1, 0, 0);
+        }
+        d_prev = tile_d_off(ti);
+        ktile(c0_t{}, buf0, buf1, false, 0, 0, 0);
+        ktile(c3_t{}, buf1, buf0, true, 1, d_prev, ti & 1);
+      }
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (my_tiles > 0) epilogue_block(my_tiles - 1, false);
+    if (my_tiles > 0) epi_rows(c1_t{}, 0, MA1, d_prev, (my_tiles - 1) & 1, false);  // row half 1 of the last tile
     if (ABL == 9) {
       if (blockIdx.x == 0 && (wave & 3) == 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1151,7 +1230,8 @@ static void launch_p8_cfg(const uint8_t* a, const uint8_t* b, uint16_t* D, const
   const int tiles_m = (int)(M / TBM), tiles_n = (int)(N / TBN);
   // one_tile_per_wg (algo 5): same kernel, one workgroup per tile, so the hardware dispatcher balances the tiles over whatever
   // CUs are free -- the form to use while other kernels (RCCL collectives) hold part of the chip
-  const int grid = (one_tile_per_wg || tiles_m * tiles_n < num_cus()) ? tiles_m * tiles_n : num_cus();
+  int grid = (one_tile_per_wg || tiles_m * tiles_n < num_cus()) ? tiles_m * tiles_n : num_cus();
+  if ((ABL == 3 || ABL == 8 || ABL == 9) && getenv("MI_GEMM_GRID")) grid = std::max(1, std::min(grid, atoi(getenv("MI_GEMM_GRID"))));  // experiment knob
   const int stagger = ((ABL == 3) && getenv("MI_GEMM_STAGGER")) ? atoi(getenv("MI_GEMM_STAGGER")) : 0;  // experiment knob (algo 16)
   hipLaunchKernelGGL((gemm_256_p8<FA, FB, ABL, MX, BIAS, MA1, NB1, false, DEPI>), dim3(grid), dim3(512), 0, st, a, b, D, sa_inv, sb_inv, (int)K,
                      (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb), (int)(M * ldd * 2), SA, SB,
@@ -1214,7 +1294,7 @@ static int launch_p8(const uint8_t* a, const uint8_t* b, uint16_t* D, const floa
     case 2: MI_P8(MXv, BIASv, ABLv, 2, 2); break;                   \
     default: MI_P8(MXv, BIASv, ABLv, 2, 1); break;                  \
   }
-  if (algo == 46 || (algo >= 15 && algo <= 24)) {  // timing-only / diagnostic builds: E4M3 x E4M3 only (compile time)
+  if (algo == 46 || (algo >= 15 && algo <= 27)) {  // timing-only / diagnostic builds: E4M3 x E4M3 only (compile time)
     if constexpr (FA == 0 && FB == 0) {
       if (algo == 46) {  // A/B baseline: block epilogue after each tile (the round-1 form)
         switch (cfg) {
@@ -1235,6 +1315,12 @@ static int launch_p8(const uint8_t* a, const uint8_t* b, uint16_t* D, const floa
         MI_P8_CFG(false, false, 9)
       } else if (algo == 21) {  // `bias` is a u64[4 * grid] stamp buffer (cycles, 100 MHz ticks, steps, XCC id)
         MI_P8_CFG(false, false, 8)
+      } else if (algo == 27) {  // epilogue woven into the MFMA segments (timing A/B)
+        MI_P8_CFG(false, false, 14)
+      } else if (algo == 25) {  // nt (streaming) stores
+        MI_P8_CFG(false, false, 12)
+      } else if (algo == 26) {  // sc1 + nt stores
+        MI_P8_CFG(false, false, 13)
       } else if (algo == 24) {  // A/B baseline: half-line epilogue stores (16 rows x 64 B per instruction)
         MI_P8_CFG(false, false, 11)
       } else if (algo == 18) {  // block scales staged into LDS but not read (unit scales): wrong results
@@ -1274,7 +1360,7 @@ static int launch_fmt(const void* A, const void* B, void* D, const float* sa_inv
     int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
     hipLaunchKernelGGL((gemm_256_8ph<FA, FB, OUT>), dim3(tiles_m * tiles_n), dim3(512), 0, st, a, b, D, sa_inv, sb_inv,
                        bp, (int)M, (int)N, (int)K, lda, ldb, ldd, tiles_m, tiles_n);
-  } else if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 24) || (algo >= 40 && algo <= 46)) {
+  } else if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 27) || (algo >= 40 && algo <= 46)) {
     return launch_p8<FA, FB>(a, b, (uint16_t*)D, sa_inv, sb_inv, (const uint8_t*)SA, (const uint8_t*)SB, bp, M, N, K, lda, ldb, ldd,
                              algo, mx, st);
   } else if (algo == 13 && !mx) {
@@ -1334,7 +1420,7 @@ static int pick_algo(int algo, int64_t M, int64_t N, int64_t K, int64_t lda, int
   const bool p8_ok = (M % 256 == 0 || M % 192 == 0) && (N % 256 == 0 || N % 192 == 0) && M > 0 && N > 0 && K > 0 &&
                      (K % (2 * BK) == 0) && out == 0 && M * lda < (1LL << 31) && N * ldb < (1LL << 31) &&
                      M * ldd * 2 < (1LL << 31);
-  if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 24) || (algo >= 40 && algo <= 46)) {
+  if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 27) || (algo >= 40 && algo <= 46)) {
     if (!p8_ok) {
       set_error("%s: algo %d needs M,N %% 256 (or 192) == 0, K %% 256 == 0, bf16 output, operands < 2 GiB", who, algo);
       return MI_ERR_SHAPE;

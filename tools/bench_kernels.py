@@ -138,6 +138,15 @@ def main():
             fns["half24"] = (lambda: ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=24))
             res = time_interleaved(fns, rounds=8, inner=6)
             print(f"stagger {m}x{n}x{k}: " + "  ".join(f"{al}: {t*1e6:7.1f} us {2.0*m*n*k/t/1e12:6.0f} TF" for al, t in res.items()), flush=True)
+    if "storepol" in args.which:  # epilogue store cache policy: sc1 (default) / plain / nt / sc1+nt / no stores, interleaved A/B
+        shapes = [(8192, 8192, 2048), (8192, 16384, 3072), (8192, 3072, 16384), (16384, 3072, 8192), (8192, 3072, 8192), (8192, 8192, 3072), (8192, 5120, 3072), (8192, 3072, 3072)]
+        for (m, n, k) in shapes:
+            a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
+            out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+            fns = {name: (lambda al=al: ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=al))
+                   for name, al in (("sc1", 4), ("plain", 17), ("nt", 25), ("sc1nt", 26), ("nostore", 15), ("block46", 46))}
+            res = time_interleaved(fns, rounds=8, inner=6)
+            print(f"storepol {m}x{n}x{k}: " + "  ".join(f"{al}: {t*1e6:7.1f} us {2.0*m*n*k/t/1e12:6.0f} TF" for al, t in res.items()), flush=True)
     if "stamps" in args.which:  # per-phase timeline of workgroup 0 (algo 22), around the tile boundaries
         from llm_fp8_amd import _lib
         lib = _lib.load()
@@ -291,6 +300,30 @@ def main():
                 print(f"pclock {m}x{n}x{k} {fill:6s}: clock median {float(clk.median()):7.1f} MHz (min {float(clk.min()):.0f} max {float(clk.max()):.0f}) "
                       f"cycles/K-tile-step median {float(cyc_per_step.median()):7.1f} (ideal 2048)  {t*1e6:8.1f} us {tf:7.1f} TF "
                       f"= {tf/5000*100:4.1f}% of 5 PF = {tf/(5000*float(clk.median())/2400)*100:4.1f}% at clock", flush=True)
+    if "gridsweep" in args.which:  # is the tile-boundary cost a per-CU or a chip-wide limit?  same per-CU work on fewer CUs (MI_GEMM_GRID, algo 21)
+        from llm_fp8_amd import _lib
+        lib = _lib.load()
+        st = torch.cuda.current_stream().cuda_stream
+        for grid in (256, 128, 64, 32):
+            os.environ["MI_GEMM_GRID"] = str(grid)
+            for (m, n, k) in ((8192 * grid // 256, 8192, 3072), (8192 * grid // 256, 8192, 8192)):
+                a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
+                out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+                dbg = torch.zeros((256, 4), dtype=torch.int64, device=dev)
+                def run(algo, bias_ptr):
+                    rc = lib.mi_gemm_fp8(a.data_ptr(), b.data_ptr(), out.data_ptr(), one.data_ptr(), one.data_ptr(), bias_ptr,
+                                         m, n, k, k, k, n, 0, 0, 0, algo, st)
+                    assert rc == 0, lib.mi_last_error()
+                for _ in range(100):
+                    run(21, dbg.data_ptr())
+                torch.cuda.synchronize()
+                d = dbg.cpu().double()
+                d = d[d[:, 1] > 0]
+                clk = d[:, 0] / d[:, 1] * 100.0
+                cyc = d[:, 0] / d[:, 2]
+                print(f"gridsweep grid {grid:3d} {m}x{n}x{k}: {len(d)} workgroups, {int(d[0, 2])} K-steps each, cycles/K-tile-step median {float(cyc.median()):7.1f} "
+                      f"(min {float(cyc.min()):.0f} max {float(cyc.max()):.0f}), clock {float(clk.median()):6.0f} MHz", flush=True)
+        os.environ.pop("MI_GEMM_GRID", None)
     if "cast" in args.which:
         for (R, C) in ((8192, 3072), (8192, 16384), (16384, 3072), (8192, 8192)):
             x = torch.randn((R, C), device=dev, dtype=torch.float32, generator=g).to(torch.bfloat16)
