@@ -281,7 +281,7 @@ def test_train_steps_run_and_update_once_per_step(te, dev, use_te, scenario):
     # the value the next forward's cast would have
     assert hist[0, 0].item() == 0 and hist[0, 2:].abs().sum().item() == 0
     from llm_fp8_amd.pytorch.module import weight_sinks_enabled
-    if not (weight_sinks_enabled() and scenario == "default"):
+    if not weight_sinks_enabled():
         assert hist[0, 1].item() == 0
     n_nonzero = int((hist[:, 0] > 0).sum().item())
     assert n_nonzero == min(6, hist.shape[0] - 1), n_nonzero

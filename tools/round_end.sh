@@ -9,6 +9,7 @@ cd $GRAFT_REPO_ROOT
 run() { name=$1; shift; timeout -k 10 400 python bench.py "$@" > $out/$name.log 2>&1 || { echo "$name FAILED"; tail -5 $out/$name.log; return 1; }
         grep "^{" $out/$name.log > $out/${tag}_$name.json; cut -c1-160 $out/${tag}_$name.json; }
 run bench_3b_default || exit 1
+run bench_3b_route_reference --route reference --no-cpu-baseline || exit 1
 run bench_3b_hybrid --scenario hybrid --no-cpu-baseline || exit 1
 run bench_3b_mxfp8 --scenario mxfp8 --no-cpu-baseline || exit 1
 run bench_1b_default --model llama-3.2-1b --no-cpu-baseline || exit 1
