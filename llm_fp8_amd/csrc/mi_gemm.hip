@@ -428,16 +428,16 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   // one LDS read instead of F byte reads (12 ds_read_u8 per K-tile cost the block-scaled GEMM 10 %).  Free on both sides:
   // the rows are gathered by the LDS-DMA source addresses, and an epilogue store covers 16 rows either way.
   constexpr bool PERM = MX;
-  // behind the operand buffers: 6 KiB for the E8M0 scales (MX: 2 slots x {A, B} x 4 k-blocks x 256 rows, padded) and 4 KiB of
-  // bias windows (BIAS: 2 slots x 8 waves x 256 B)
-  __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes + ((MX || BIAS) ? 10240 : 0) + (ABL == 9 ? 16384 : 0)];
+  // behind the operand buffers: 8 KiB for the E8M0 scales (MX: 2 slots of 4 KiB x {A, B} x 4 k-blocks x 256 rows, padded) and
+  // 4 KiB of bias windows (BIAS: 2 slots x 8 waves x 256 B)
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes + ((MX || BIAS) ? 12288 + 256 : 0) + (ABL == 9 ? 16384 : 0)];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   // ABL == 9 (diagnostic build, algo 22): waves 0 and 4 of workgroup 0 stamp s_memtime at the start of every MFMA segment and at
   // the end of every phase into LDS (2 x 1024 stamps) and dump them to the u64 buffer passed as `bias` when the kernel ends
   int stamp_idx = 0;
-  unsigned long long* const stamp_lds = reinterpret_cast<unsigned long long*>(lds + kLdsBytes + ((MX || BIAS) ? 10240 : 0)) + (wave >> 2) * 1024;
+  unsigned long long* const stamp_lds = reinterpret_cast<unsigned long long*>(lds + kLdsBytes + ((MX || BIAS) ? 12288 + 256 : 0)) + (wave >> 2) * 1024;
   auto stamp = [&]() {
     if (ABL == 9) {
       if (blockIdx.x == 0 && (wave & 3) == 0 && stamp_idx < 1024) {
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   // 0..3 of rows r..r+15) then fall on disjoint banks; at a 256-B stride they were a 4-way conflict on an LDS that the
   // fragment reads already keep 75 % busy, and the block-scaled GEMM ran 10 % behind the per-tensor one
   // LDS: [2 slots][operand A, B][4 k-blocks][272]
-  constexpr int kSK = 272, kSOp = 4 * kSK, kSSlot = 2 * kSOp;
+  constexpr int kSK = 272, kSOp = 4 * kSK, kSSlot = 4096;  // slot stride: a power of two, so the read bases toggle by v_xor (2 * kSOp = 2176 B used)
   uint8_t* const sbuf = lds + kLdsBytes;
   auto stage_scales = [&](int slot, int kt, int row0a, int row0b) {
     if (MX) {
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   // bias: every K-tile each wave re-fetches the 256-byte window that starts at its own columns of cursor 1's tile
   // (one dword per lane; reads past N return 0 through the descriptor's range check) -> uniform vmcnt accounting
   const rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)(BIAS ? (const void*)bias : (const void*)A), 0, BIAS ? N * 2 : 0, 0x00020000);
-  uint8_t* const bbuf = lds + kLdsBytes + 6144;  // [slot][wave][256 B]
+  uint8_t* const bbuf = lds + kLdsBytes + 8192;  // [slot][wave][256 B]
   auto stage_bias = [&](int slot, int col0) {
     if (BIAS)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsBias, LDS_PTR(bbuf + (slot * 8 + wave) * 256), 4, lane * 4,
@@ -574,9 +574,26 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
     tile_mn(min(lane, max(total_tiles_hint - 1, 0)), tm, tn);
     tab = tm | (tn << 16);
   }
+  // MX variants (no VGPR to spare: the table register was spilled and reloaded by a scratch load in EVERY K-tile's cursor
+  // advance, an uncounted op in front of the counted waits): the table lives in LDS behind the bias windows instead and a tile
+  // switch reads its entry with one uniform ds_read (+ lgkmcnt wait, once per cursor and tile).
+  constexpr bool kTabLds = MX;
+  const unsigned tab_lds = (unsigned)(size_t)LDS_PTR(lds + kLdsBytes + 8192 + 4096);  // 256 B; the MX / BIAS region is 12288 + 256 B
+  if (kTabLds) {
+    if (wave == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(tab_lds + lane * 4), "v"(tab) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // all 8 waves: the first tile_rc follows at once
+  }
   auto tile_rc = [&](int ti, int& ra, int& rb) {
     if (ti < 64) {
-      const int t = __builtin_amdgcn_readlane(tab, ti);
+      int t;
+      if (kTabLds) {
+        int v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(tab_lds + ti * 4) : "memory");
+        t = __builtin_amdgcn_readfirstlane(v);
+      } else {
+        t = __builtin_amdgcn_readlane(tab, ti);
+      }
       ra = (t & 0xFFFF) * TBM;
       rb = (int)((unsigned)t >> 16) * TBN;
     } else {
@@ -663,13 +680,25 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
       fb1_hi = l0 + kOffB1 + wc * NB1 * 2048 + fhi;
     }
   }
+  // MX: per-lane LDS byte addresses of this lane's block scales in the CURRENT scale slot: A side = 4 (MA1) consecutive bytes per
+  // k-block (row slot sfr of the wave's fragment rows, see PERM), B side = one byte per fragment at +16 j.  Same reason as the
+  // fragment bases: left to hipcc, every (slot, operand half) x (lane part) sum becomes a hoisted VGPR, and the 256x256 MX
+  // variants spilled ten of them.
+  int sc_a = 0, sc_a1 = 0, sc_b = 0;
+  if (MX) {
+    const int s0 = (int)(size_t)LDS_PTR(sbuf) + sfq * kSK;
+    sc_a = s0 + wr * (RA0 + RA1) + 4 * sfr;
+    sc_a1 = s0 + wr * (RA0 + RA1) + RA0 + (MA1 == 4 ? 4 : 2) * sfr;
+    sc_b = s0 + kSOp + wc * (RB0 + RB1) + sfr;
+  }
   auto frag_toggle = [&]() __attribute__((always_inline)) {
+    if (MX) asm volatile("v_xor_b32 %0, 0x1000, %0\n\tv_xor_b32 %1, 0x1000, %1\n\tv_xor_b32 %2, 0x1000, %2" : "+v"(sc_a), "+v"(sc_a1), "+v"(sc_b));
     asm volatile("v_xor_b32 %0, 0x10000, %0\n\tv_xor_b32 %1, 0x10000, %1\n\tv_xor_b32 %2, 0x10000, %2\n\tv_xor_b32 %3, 0x10000, %3"
                  : "+v"(fa_lo), "+v"(fa_hi), "+v"(fb_lo), "+v"(fb_hi));
     if (MA1 != 4) asm volatile("v_xor_b32 %0, 0x10000, %0\n\tv_xor_b32 %1, 0x10000, %1" : "+v"(fa1_lo), "+v"(fa1_hi));
     if (NB1 != 2) asm volatile("v_xor_b32 %0, 0x10000, %0\n\tv_xor_b32 %1, 0x10000, %1" : "+v"(fb1_lo), "+v"(fb1_hi));
   };
-  static_assert(kBufBytes == 0x10000, "frag_toggle assumes 64-KiB buffers");
+  static_assert(kBufBytes == 0x10000 && kSSlot == 0x1000 && (kLdsBytes % 0x2000) == 0, "frag_toggle assumes 64-KiB buffers and 4-KiB scale slots at an 8-KiB boundary");
   int s = 0;  // current step
   // One K-tile = 4 phases; LDS-DMA issued per phase: p0 {EX, B1(step+1): nB1}, p1 {A1(step+1): nA1}, p2 {A0(step+2): 2},
   // p3 {B0(step+2): 2}; fragments read at the TOP of a phase (before its wait + barrier): p0 A0/B0, p1 B1, p2 A1.
@@ -925,8 +954,6 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
     using wv23_t = std::integral_constant<int, (kWoven ? nr23_t::value : 0)>;
     using ma1_t = std::integral_constant<int, MA1>;
     using nb1_t = std::integral_constant<int, NB1>;
-    const uint8_t* sc = sbuf + slot * kSSlot + sfq * kSK + sfr;  // A scales: + tile row of the fragment
-    const uint8_t* scb = sc + kSOp;                              // B scales
     const int sa1 = oa_1 + kt_1 * BK, sb1 = ob_1 + kt_1 * BK;
     const int sa2 = oa_2 + kt_2 * BK, sb2 = ob_2 + kt_2 * BK;
     // Fragment reads: explicit per-lane bases (fa_* / fb_*, see their definition) + immediate offsets -- no address VALU in the
@@ -959,14 +986,15 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
 #pragma unroll
     for (int i = 0; i < 4; ++i) af[i] = frag(kOffA0, wr * 4, i);
     if (MX && ABL != 5) {  // every scale of this K-tile up front: phases 1-3 then start on their fragment reads alone
+      // (inline asm: the values are consumed behind MI_WAIT_SYNC's `s_waitcnt lgkmcnt(0)` + sched_barrier, like the fragments)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b0s[j] = scb[wc * (RB0 + RB1) + j * 16];
+      for (int j = 0; j < 2; ++j) asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(b0s[j]) : "v"(sc_b), "n"(j * 16));
 #pragma unroll
-      for (int j = 0; j < NB1; ++j) b1s[j] = scb[wc * (RB0 + RB1) + RB0 + j * 16];
+      for (int j = 0; j < NB1; ++j) asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(b1s[j]) : "v"(sc_b), "n"(RB0 + j * 16));
       // A side: the lane's 4 (A0) and MA1 (A1) fragment scales as one dword / one u16 (sfr = row slot, see PERM)
-      as_[0] = *reinterpret_cast<const int*>(sc - sfr + wr * (RA0 + RA1) + 4 * sfr);
-      if (MA1 == 4) as1[0] = *reinterpret_cast<const int*>(sc - sfr + wr * (RA0 + RA1) + RA0 + 4 * sfr);
-      else as1[0] = *reinterpret_cast<const uint16_t*>(sc - sfr + wr * (RA0 + RA1) + RA0 + 2 * sfr);
+      asm volatile("ds_read_b32 %0, %1" : "=v"(as_[0]) : "v"(sc_a));
+      if (MA1 == 4) asm volatile("ds_read_b32 %0, %1" : "=v"(as1[0]) : "v"(sc_a1));
+      else asm volatile("ds_read_u16 %0, %1" : "=v"(as1[0]) : "v"(sc_a1));
       if (ABL == 6) {  // timing ablation: the scales are read but the MFMAs get unit scales
         asm volatile("" ::"v"(as_[0]), "v"(as1[0]));
         as_[0] = kUnitScale;

@@ -1,3 +1,5 @@
+import signal
+signal.signal(signal.SIGPIPE, signal.SIG_DFL)
 import sys, json
 l=[x for x in open(sys.argv[1]) if x.startswith('{')][-1]
 d=json.loads(l)
