@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi_fp8.so")
+LIB_PATH = os.environ.get("LLM_FP8_AMD_LIB") or os.path.join(_HERE, "libmi_fp8.so")  # the override is for A/B timing of another build of the same ABI
 
 MI_FMT_E4M3 = 0
 MI_FMT_E5M2 = 1

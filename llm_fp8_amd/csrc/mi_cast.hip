@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void cast_amax_kernel(const uint16_t* __restri
       if (WRITE_Y) {
         uint8_t* dst = y + (int64_t)r0 * ld_y + c0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<uint2*>(dst + (int64_t)i * ld_y) = make_uint2(lo[i], hi[i]);
+        for (int i = 0; i < 8; ++i) mi::st8<MI_NT_Y>(dst + (int64_t)i * ld_y, lo[i], hi[i]);
       }
       if (WRITE_T) {
         u32 a[4], b[4], c[4], d[4];
@@ -104,8 +104,8 @@ __global__ __launch_bounds__(256) void cast_amax_kernel(const uint16_t* __restri
         uint8_t* dst = yT + (int64_t)c0 * ld_yT + r0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          *reinterpret_cast<uint2*>(dst + (int64_t)j * ld_yT) = make_uint2(a[j], b[j]);
-          *reinterpret_cast<uint2*>(dst + (int64_t)(j + 4) * ld_yT) = make_uint2(c[j], d[j]);
+          mi::st8<MI_NT_YT>(dst + (int64_t)j * ld_yT, a[j], b[j]);
+          mi::st8<MI_NT_YT>(dst + (int64_t)(j + 4) * ld_yT, c[j], d[j]);
         }
       }
     }
@@ -279,8 +279,8 @@ __global__ __launch_bounds__(256) void transpose_u8_kernel(const uint8_t* __rest
   uint8_t* dst = yT + c0 * ld_yT + r0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    *reinterpret_cast<uint2*>(dst + (int64_t)j * ld_yT) = make_uint2(a[j], b[j]);
-    *reinterpret_cast<uint2*>(dst + (int64_t)(j + 4) * ld_yT) = make_uint2(c[j], d[j]);
+    mi::st8<MI_NT_YT>(dst + (int64_t)j * ld_yT, a[j], b[j]);
+    mi::st8<MI_NT_YT>(dst + (int64_t)(j + 4) * ld_yT, c[j], d[j]);
   }
 }
 }  // namespace mi

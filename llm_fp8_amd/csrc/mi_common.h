@@ -120,3 +120,23 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 }  // namespace mi
+// 8-byte FP8 stores of the cast / quantise kernels (one 8 x 8 block per lane: 8 lanes = one 64-byte row segment).
+// MI_NT_Y / MI_NT_YT (build-time, timing experiments): nontemporal stores for the row-major / the transposed copy.
+#ifndef MI_NT_Y
+#define MI_NT_Y 0
+#endif
+#ifndef MI_NT_YT
+#define MI_NT_YT 0
+#endif
+#if defined(__HIPCC__)
+namespace mi {
+template <bool NT>
+__device__ __forceinline__ void st8(uint8_t* p, unsigned int a, unsigned int b) {
+  typedef unsigned int v2u_st8 __attribute__((ext_vector_type(2)));
+  const v2u_st8 w = {a, b};
+  if (NT) __builtin_nontemporal_store(w, reinterpret_cast<v2u_st8*>(p));
+  else *reinterpret_cast<v2u_st8*>(p) = w;
+}
+}  // namespace mi
+#endif
+

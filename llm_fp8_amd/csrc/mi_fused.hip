@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void rope_bwd_cast_kernel(const uint16_t* __re
     if (WRITE_Y) {
       uint8_t* dst = y + (int64_t)r0 * W + c0;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) *reinterpret_cast<uint2*>(dst + (int64_t)i * W) = make_uint2(lo[i], hi[i]);
+      for (int i = 0; i < 8; ++i) mi::st8<MI_NT_Y>(dst + (int64_t)i * W, lo[i], hi[i]);
     }
     if (WRITE_T) {
       u32 a[4], b[4], c[4], d[4];
@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256) void rope_bwd_cast_kernel(const uint16_t* __re
       uint8_t* dst = yT + (int64_t)c0 * rows + r0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        *reinterpret_cast<uint2*>(dst + (int64_t)j * rows) = make_uint2(a[j], b[j]);
-        *reinterpret_cast<uint2*>(dst + (int64_t)(j + 4) * rows) = make_uint2(c[j], d[j]);
+        mi::st8<MI_NT_YT>(dst + (int64_t)j * rows, a[j], b[j]);
+        mi::st8<MI_NT_YT>(dst + (int64_t)(j + 4) * rows, c[j], d[j]);
       }
     }
   };
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void swiglu_cast_kernel(const uint16_t* __rest
       if (WRITE_Y) {
         uint8_t* dst = y + (int64_t)r0 * ocols + c0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<uint2*>(dst + (int64_t)i * ocols) = make_uint2(lo[o][i], hi[o][i]);
+        for (int i = 0; i < 8; ++i) mi::st8<MI_NT_Y>(dst + (int64_t)i * ocols, lo[o][i], hi[o][i]);
       }
       if (WRITE_T) {
         u32 a[4], b[4], c[4], dd[4];
@@ -277,8 +277,8 @@ __global__ __launch_bounds__(256) void swiglu_cast_kernel(const uint16_t* __rest
         uint8_t* dst = yT + (int64_t)c0 * rows + r0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          *reinterpret_cast<uint2*>(dst + (int64_t)j * rows) = make_uint2(a[j], b[j]);
-          *reinterpret_cast<uint2*>(dst + (int64_t)(j + 4) * rows) = make_uint2(c[j], dd[j]);
+          mi::st8<MI_NT_YT>(dst + (int64_t)j * rows, a[j], b[j]);
+          mi::st8<MI_NT_YT>(dst + (int64_t)(j + 4) * rows, c[j], dd[j]);
         }
       }
     }
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void norm_cast_kernel(const uint16_t* __restri
     if (WRITE_Y) {
       uint8_t* dst = y + (int64_t)r0 * cols + c0;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) *reinterpret_cast<uint2*>(dst + (int64_t)i * cols) = make_uint2(lo[i], hi[i]);
+      for (int i = 0; i < 8; ++i) mi::st8<MI_NT_Y>(dst + (int64_t)i * cols, lo[i], hi[i]);
     }
     if (WRITE_T) {
       u32 a[4], b[4], c[4], d[4];
@@ -410,8 +410,8 @@ __global__ __launch_bounds__(256) void norm_cast_kernel(const uint16_t* __restri
       uint8_t* dst = yT + (int64_t)c0 * rows + r0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        *reinterpret_cast<uint2*>(dst + (int64_t)j * rows) = make_uint2(a[j], b[j]);
-        *reinterpret_cast<uint2*>(dst + (int64_t)(j + 4) * rows) = make_uint2(c[j], d[j]);
+        mi::st8<MI_NT_YT>(dst + (int64_t)j * rows, a[j], b[j]);
+        mi::st8<MI_NT_YT>(dst + (int64_t)(j + 4) * rows, c[j], d[j]);
       }
     }
   }
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(256) void ce_bwd_cast_kernel(const uint16_t* __rest
     if (WRITE_Y) {
       uint8_t* dst = y + (int64_t)r0 * cols + c0;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) *reinterpret_cast<uint2*>(dst + (int64_t)i * cols) = make_uint2(lo[i], hi[i]);
+      for (int i = 0; i < 8; ++i) mi::st8<MI_NT_Y>(dst + (int64_t)i * cols, lo[i], hi[i]);
     }
     if (WRITE_T) {
       u32 a[4], b[4], c[4], d[4];
@@ -666,8 +666,8 @@ __global__ __launch_bounds__(256) void ce_bwd_cast_kernel(const uint16_t* __rest
       uint8_t* dst = yT + (int64_t)c0 * rows + r0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        *reinterpret_cast<uint2*>(dst + (int64_t)j * rows) = make_uint2(a[j], b[j]);
-        *reinterpret_cast<uint2*>(dst + (int64_t)(j + 4) * rows) = make_uint2(c[j], d[j]);
+        mi::st8<MI_NT_YT>(dst + (int64_t)j * rows, a[j], b[j]);
+        mi::st8<MI_NT_YT>(dst + (int64_t)(j + 4) * rows, c[j], d[j]);
       }
     }
   }

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
     if (active) {
       uint8_t* dst = y_row + (int64_t)r0 * cols + c0;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) *reinterpret_cast<uint2*>(dst + (int64_t)i * cols) = make_uint2(lo[i], hi[i]);
+      for (int i = 0; i < 8; ++i) mi::st8<MI_NT_Y>(dst + (int64_t)i * cols, lo[i], hi[i]);
       if ((lane & 3) == 0) {  // block-major scales [cols/32, rows]: this lane's 8 rows are 8 contiguous bytes
         const u32 lo4 = sbytes[0] | (sbytes[1] << 8) | (sbytes[2] << 16) | (sbytes[3] << 24);
         const u32 hi4 = sbytes[4] | (sbytes[5] << 8) | (sbytes[6] << 16) | (sbytes[7] << 24);
@@ -277,8 +277,8 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const uint16_t* __rest
       uint8_t* dst = y_colT + (int64_t)c0 * ldr + r0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        *reinterpret_cast<uint2*>(dst + (int64_t)j * ldr) = make_uint2(a[j], b[j]);
-        *reinterpret_cast<uint2*>(dst + (int64_t)(j + 4) * ldr) = make_uint2(c[j], d[j]);
+        mi::st8<MI_NT_YT>(dst + (int64_t)j * ldr, a[j], b[j]);
+        mi::st8<MI_NT_YT>(dst + (int64_t)(j + 4) * ldr, c[j], d[j]);
       }
       if (((lane >> 3) & 3) == 0) {  // block-major scales [rows/32, cols]: 8 contiguous bytes for this lane's 8 columns
         const u32 lo4 = sbytes[0] | (sbytes[1] << 8) | (sbytes[2] << 16) | (sbytes[3] << 24);

@@ -5,6 +5,7 @@ per parameter group (device tables of tensor addresses + a chunk list).  bf16 pa
 `exp_avg` / `exp_avg_sq`, fp32 math -- the state layout of torch's fused AdamW, so `state_dict()` is interchangeable."""
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -37,6 +38,8 @@ class ClippedAdamW(torch.optim.Optimizer):
     @staticmethod
     def _sink_of(p):
         """(sink, row offset, rows) when the FP8 copies of this weight are kept current by the optimiser (module.WeightSink)."""
+        if os.environ.get("LLM_FP8_AMD_NO_OPT_WCAST") == "1":  # the switch of module.weight_sinks_enabled: the forward casts
+            return None
         s = getattr(p, "_mi_fp8_sink", None)
         sh = getattr(p, "_mi_shard_of", None)
         if sh is not None:  # a row shard of a master weight (distributed.ShardedFP8DP): rows [r0, r0 + n) of the full operand part
@@ -94,8 +97,9 @@ class ClippedAdamW(torch.optim.Optimizer):
                 sink, r0, _ = s
                 K, N = p.shape[1], sink.w8.shape[0]
                 rows[5].append(K)
-                rows[6].append(sink.w8.data_ptr() + r0 * K)
-                rows[7].append(sink.w8t.data_ptr() + r0)
+                dbg = os.environ.get("MI_DEBUG_SINK", "full")  # tools/bench_adamw.py: mask the FP8 outputs off (timing only)
+                rows[6].append(0 if dbg == "none" else sink.w8.data_ptr() + r0 * K)
+                rows[7].append(0 if dbg in ("none", "noT") else sink.w8t.data_ptr() + r0)
                 rows[8].append(K)
                 rows[9].append(N)
                 rows[10].append(sink.scale.data_ptr())
