@@ -177,6 +177,27 @@ def replace_decoder(te_decoder_cls):
         mod.LlamaDecoderLayer = original
 
 
+def _drop_padding_mask(module, args, kwargs):
+    """Forward pre-hook of the HF `LlamaModel` that carries TE decoder layers.  Their attention core is causal and, as TE does
+    with `attn_mask_type="causal"` (te_llama.py:45-56), ignores a padding mask, so the 4-D mask HF would build from
+    `attention_mask` is read by nobody -- but building it costs a host synchronisation per forward (`padding_mask.all()` with a
+    2-D mask, the packed-sequence check `(...).all()` on `position_ids` with no mask; transformers' masking_utils): the CPU
+    waits for the previous step to drain and the GPU then idles ~0.5 ms while the first kernels of the step are enqueued.  A
+    mask that is already 4-D is passed through untouched by HF ("already prepared"), so a 2-D / missing mask is replaced by a
+    one-element 4-D placeholder.  The outputs do not depend on the mask either way."""
+    am = kwargs.get("attention_mask", None)
+    if am is None or (isinstance(am, torch.Tensor) and am.dim() != 4):
+        ref = kwargs.get("input_ids", None)
+        if ref is None:
+            ref = kwargs.get("inputs_embeds", None)
+        if ref is None and args:
+            ref = args[0]
+        if isinstance(ref, torch.Tensor):
+            kwargs = dict(kwargs)
+            kwargs["attention_mask"] = torch.ones((1, 1, 1, 1), dtype=torch.bool, device=ref.device)
+    return args, kwargs
+
+
 class TELlamaForCausalLM:
     """te_llama.py:85-98: HF owns embeddings / final norm / lm_head / loss, our layers own the decoder."""
 
@@ -184,6 +205,7 @@ class TELlamaForCausalLM:
         from transformers.models.llama.modeling_llama import LlamaForCausalLM
         with replace_decoder(te_decoder_cls=decoder_layer_cls(scenario)):
             model = LlamaForCausalLM(config)
+        model.model.register_forward_pre_hook(_drop_padding_mask, with_kwargs=True)
         return model
 
     @classmethod
