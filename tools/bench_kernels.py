@@ -139,7 +139,8 @@ def main():
             res = time_interleaved(fns, rounds=8, inner=6)
             print(f"stagger {m}x{n}x{k}: " + "  ".join(f"{al}: {t*1e6:7.1f} us {2.0*m*n*k/t/1e12:6.0f} TF" for al, t in res.items()), flush=True)
     if "storepol" in args.which:  # epilogue store cache policy: sc1 (default) / plain / nt / sc1+nt / no stores, interleaved A/B
-        shapes = [(8192, 8192, 2048), (8192, 16384, 3072), (8192, 3072, 16384), (16384, 3072, 8192), (8192, 3072, 8192), (8192, 8192, 3072), (8192, 5120, 3072), (8192, 3072, 3072)]
+        shapes = [(8192, 8192, 2048), (8192, 16384, 3072), (8192, 3072, 16384), (16384, 3072, 8192), (8192, 3072, 8192), (8192, 8192, 3072), (8192, 5120, 3072), (8192, 3072, 3072),
+                  (8192, 128256, 3072), (128256, 3072, 8192), (8192, 28672, 4096), (6144, 28672, 4096)]
         for (m, n, k) in shapes:
             a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
             out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
