@@ -91,3 +91,29 @@ def test_committed_bench_line_has_the_contract_fields():
     assert c["kind"] in ("port", "reference")
     tokens = 16 * 512 * d["n_gpus"]
     assert abs(d["value"] - tokens / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
+def test_padding_mask_never_reaches_hfs_mask_builder():
+    """te_llama.py:68-82 forwards `attention_mask`, TE's causal core ignores it.  HF's mask builder would synchronise the host on
+    it once per forward; the model hands it a 4-D placeholder instead (llama._drop_padding_mask).  Outputs must not change."""
+    import torch
+    from transformers import LlamaConfig
+    from llm_fp8_amd import llama
+    cfg = LlamaConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                      vocab_size=256, max_position_embeddings=128)
+    torch.manual_seed(0)
+    model = llama.TELlamaForCausalLM(cfg)
+    ids = torch.randint(0, 256, (2, 32))
+    seen = []
+    h = model.model.layers[0].register_forward_pre_hook(lambda m, a, kw: seen.append(kw.get("attention_mask")), with_kwargs=True)
+    with torch.no_grad():
+        with_mask = model(input_ids=ids, attention_mask=torch.ones_like(ids)).logits
+        no_mask = model(input_ids=ids).logits
+        four_d = torch.ones((2, 1, 32, 32), dtype=torch.bool).tril()
+        model(input_ids=ids, attention_mask=four_d)
+        h.remove()
+        model.model._forward_pre_hooks.clear()  # HF's own path (2-D mask -> its builder)
+        plain = model(input_ids=ids, attention_mask=torch.ones_like(ids)).logits
+    assert torch.equal(with_mask, no_mask) and torch.equal(with_mask, plain)
+    assert seen[0] is not None and seen[0].dim() == 4 and seen[0].numel() == 1  # the placeholder reached the decoder layers
+    assert seen[2] is four_d or (seen[2].shape == four_d.shape)  # a caller's prepared 4-D mask is passed through untouched
