@@ -81,7 +81,9 @@ def main():
                 print(f"algos {name:4s} {kind:5s} {m}x{n}x{k}: " + "  ".join(f"algo {al}: {t*1e6:7.1f} us {2.0*m*n*k/t/1e12:6.0f} TF" for al, t in res.items()), flush=True)
     if "tiles" in args.which:
         for (m, n, k) in ((8192, 3072, 3072), (8192, 3072, 8192), (3072, 8192, 8192), (3072, 3072, 8192), (8192, 3072, 16384),
-                          (8192, 6144, 3072), (6144, 6144, 4096), (8192, 3072, 5120), (8192, 5120, 3072), (5120, 3072, 8192)):
+                          (8192, 6144, 3072), (6144, 6144, 4096), (8192, 3072, 5120), (8192, 5120, 3072), (5120, 3072, 8192),
+                          (6144, 4096, 4096), (4096, 4096, 6144), (6144, 4096, 6144), (6144, 4096, 14336), (4096, 14336, 6144), (6144, 14336, 4096),
+                          (6144, 28672, 4096), (6144, 4096, 28672), (28672, 4096, 6144), (8192, 2048, 2048), (8192, 3072, 2048), (3072, 2048, 8192), (8192, 2048, 8192), (2048, 8192, 8192)):
             a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
             out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
             fns = {}
@@ -90,6 +92,7 @@ def main():
                 if m % bm or n % bn or (algo == 44 and ((m // 256) * (n // 256) <= 256 or (m // 256) * (n // 256) % 256 == 0)):
                     continue
                 fns[algo] = (lambda al: (lambda: ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=al)))(algo)
+            fns[4] = (lambda: ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=4))  # the picker's choice
             res = time_interleaved(fns)
             print(f"tiles {m}x{n}x{k}: " + "  ".join(f"algo {al}: {t*1e6:7.1f} us {2.0*m*n*k/t/1e12:6.0f} TF" for al, t in res.items()), flush=True)
     if "mxab" in args.which:  # interleaved A/B: per-tensor-scaled vs block-scaled GEMM (same persistent kernel, MX adds the scale path)
