@@ -797,6 +797,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   auto epi_step = [&](auto a_c, int i, int st, int d_tile, bool zero, bool first) __attribute__((always_inline)) {
     constexpr int a = decltype(a_c)::value;
     constexpr int F = a == 0 ? 4 : MA1;
+    if (ABL == 15) return;  // timing build (algo 28): no epilogue at all -- neither conversion nor stores (wrong results)
     auto biased = [&](v4f v, int b, int j) __attribute__((always_inline)) -> v4f {
       if (BIAS) {
         v[0] += __uint_as_float(bias_w[b][j].x << 16);
@@ -1324,7 +1325,7 @@ static int launch_p8(const uint8_t* a, const uint8_t* b, uint16_t* D, const floa
     case 2: MI_P8(MXv, BIASv, ABLv, 2, 2); break;                   \
     default: MI_P8(MXv, BIASv, ABLv, 2, 1); break;                  \
   }
-  if (algo == 46 || (algo >= 15 && algo <= 27)) {  // timing-only / diagnostic builds: E4M3 x E4M3 only (compile time)
+  if (algo == 46 || (algo >= 15 && algo <= 28)) {  // timing-only / diagnostic builds: E4M3 x E4M3 only (compile time)
     if constexpr (FA == 0 && FB == 0) {
       if (algo == 46) {  // A/B baseline: block epilogue after each tile (the round-1 form)
         switch (cfg) {
@@ -1345,6 +1346,8 @@ static int launch_p8(const uint8_t* a, const uint8_t* b, uint16_t* D, const floa
         MI_P8_CFG(false, false, 9)
       } else if (algo == 21) {  // `bias` is a u64[4 * grid] stamp buffer (cycles, 100 MHz ticks, steps, XCC id)
         MI_P8_CFG(false, false, 8)
+      } else if (algo == 28) {  // no epilogue at all (timing only): what conversion + stores cost together
+        MI_P8_CFG(false, false, 15)
       } else if (algo == 27) {  // epilogue woven into the MFMA segments (timing A/B)
         MI_P8_CFG(false, false, 14)
       } else if (algo == 25) {  // nt (streaming) stores
@@ -1390,7 +1393,7 @@ static int launch_fmt(const void* A, const void* B, void* D, const float* sa_inv
     int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
     hipLaunchKernelGGL((gemm_256_8ph<FA, FB, OUT>), dim3(tiles_m * tiles_n), dim3(512), 0, st, a, b, D, sa_inv, sb_inv,
                        bp, (int)M, (int)N, (int)K, lda, ldb, ldd, tiles_m, tiles_n);
-  } else if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 27) || (algo >= 40 && algo <= 46)) {
+  } else if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 28) || (algo >= 40 && algo <= 46)) {
     return launch_p8<FA, FB>(a, b, (uint16_t*)D, sa_inv, sb_inv, (const uint8_t*)SA, (const uint8_t*)SB, bp, M, N, K, lda, ldb, ldd,
                              algo, mx, st);
   } else if (algo == 13 && !mx) {
@@ -1450,7 +1453,7 @@ static int pick_algo(int algo, int64_t M, int64_t N, int64_t K, int64_t lda, int
   const bool p8_ok = (M % 256 == 0 || M % 192 == 0) && (N % 256 == 0 || N % 192 == 0) && M > 0 && N > 0 && K > 0 &&
                      (K % (2 * BK) == 0) && out == 0 && M * lda < (1LL << 31) && N * ldb < (1LL << 31) &&
                      M * ldd * 2 < (1LL << 31);
-  if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 27) || (algo >= 40 && algo <= 46)) {
+  if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 28) || (algo >= 40 && algo <= 46)) {
     if (!p8_ok) {
       set_error("%s: algo %d needs M,N %% 256 (or 192) == 0, K %% 256 == 0, bf16 output, operands < 2 GiB", who, algo);
       return MI_ERR_SHAPE;
