@@ -732,7 +732,10 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
                       : (MODE_) == 2 ? ((PH) == 0 ? MA1 : 0)                                                       \
                       : (MODE_) == 3 ? ((PH) == 2 ? 4 : (PH) == 3 ? 8 : 0)                                         \
                                      : ((PH) == 0 ? MA1 : (PH) == 2 ? 4 : (PH) == 3 ? 8 : 0);                      \
-    constexpr int kX = (MODE_) == 0 ? ((PH) != 3 ? NST : 0) : kWoven ? kXw : kXl;                                  \
+    constexpr int kXh = (MODE_) == 1 ? ((PH) == 0 ? 8 : (PH) == 1 ? 8 + MA1 : (PH) == 2 ? 8 + 2 * MA1 : 4 + 2 * MA1) \
+                      : (MODE_) == 2 ? ((PH) == 0 ? 2 * MA1 : (PH) == 1 ? MA1 : 0)                                 \
+                                     : ((PH) == 3 ? 4 : 0);                                                        \
+    constexpr int kX = (MODE_) == 0 ? ((PH) != 3 ? NST : 0) : kHybrid ? kXh : kWoven ? kXw : kXl;                  \
     constexpr bool kOwn = (MODE_) >= 3 && (PH) >= 2; /* this tile's own half 0: unconditional */                   \
     if (kX != 0 && ((flag) || kOwn)) {                                                                             \
       if ((MODE_) == 4 && (PH) == 0 && !(flag)) wait_vmcnt<kAllow>();                                              \
@@ -779,7 +782,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   // store 2 = rows 8-15 x 128 B.
   typedef unsigned int v2u_ __attribute__((ext_vector_type(2)));
   v2u_ bias_w[2][2];  // BIAS: this wave's bias window (bf16 x 4 per lane and MFMA tile), read once per segment
-  v4i e_o0, e_o1;     // sub-step state of the row in flight
+  v4i e_p[2][2];      // sub-step state of the rows in flight: [slot][column block] (slot 1: the hybrid placement keeps two rows)
   auto epi_begin = [&](int bslot) __attribute__((always_inline)) {
     if (BIAS) {
       // This wave's own LDS-DMA data, landed long ago (covered by the vmcnt waits of the previous K-tiles), so no vmcnt wait is
@@ -794,7 +797,9 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
           asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(bias_w[b][j]) : "v"(bp), "n"((b * RB0 + j * 16) * 2));
     }
   };
-  auto epi_step = [&](auto a_c, int i, int st, int d_tile, bool zero, bool first) __attribute__((always_inline)) {
+  auto epi_step = [&](auto a_c, int i, int st, int d_tile, bool zero, bool first, int slot = 0) __attribute__((always_inline)) {
+    v4i& e_o0 = e_p[slot][0];
+    v4i& e_o1 = e_p[slot][1];
     constexpr int a = decltype(a_c)::value;
     constexpr int F = a == 0 ? 4 : MA1;
     if (ABL == 15) return;  // timing build (algo 28): no epilogue at all -- neither conversion nor stores (wrong results)
@@ -876,6 +881,8 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
       }
     }
   };
+  // kHybrid (ABL 16, algo 29, timing build): conversion woven into the MFMA segments, stores one load segment later
+  constexpr bool kHybrid = ABL == 16;
   using c0_t = std::integral_constant<int, 0>;
   using c1_t = std::integral_constant<int, 1>;
   using c2_t = std::integral_constant<int, 2>;
@@ -904,7 +911,8 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   auto mseg = [&](auto ni_c, auto nj_c, auto mf, auto a_c, auto nr_c, int r0, bool on, int d_tile, int bslot, bool zero)
                   __attribute__((always_inline)) {
     constexpr int NI = decltype(ni_c)::value, NJ = decltype(nj_c)::value, NM = NI * NJ;
-    constexpr int NR = decltype(nr_c)::value, NE = 4 * NR, MAXU = NR == 0 ? 0 : (NE + NM - 1) / NM;
+    constexpr int SPR = kHybrid ? 3 : 4;  // sub-steps per row woven here (hybrid: the stores follow in the NEXT load segment)
+    constexpr int NR = decltype(nr_c)::value, NE = SPR * NR, MAXU = NR == 0 ? 0 : (NE + NM - 1) / NM;
     if (NR > 0 && on) epi_begin(bslot);
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -917,7 +925,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
 #pragma unroll
             for (int u = 0; u < MAXU; ++u) {
               const int e = k * NE / NM + u;
-              if (e < (k + 1) * NE / NM) epi_step(a_c, r0 + e / 4, e % 4, d_tile, zero, e < 4);
+              if (e < (k + 1) * NE / NM) epi_step(a_c, r0 + e / SPR, e % SPR, d_tile, zero, e < SPR, kHybrid ? e / SPR : 0);
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -930,7 +938,18 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   // path takes 22 cycles per 1-KiB store, and 4 waves store at once) also cannot issue its next MFMA, so the matrix pipe idles
   // either way, and in a load segment the partner group's MFMAs at least run undisturbed.  kWoven (ABL 14, algo 27) keeps the
   // woven form as a timing build.
-  constexpr bool kWoven = ABL == 14;
+  constexpr bool kWoven = ABL == 14 || ABL == 16;
+  // hybrid: the stores of the NR rows [r0, r0 + NR) of half a that the previous MFMA segment converted (slots 0 .. NR - 1)
+  auto lseg_store = [&](auto a_c, auto nr_c, int r0, bool on, int d_tile) __attribute__((always_inline)) {
+    constexpr int NR = decltype(nr_c)::value;
+    if (NR > 0 && kHybrid) {
+      if (on) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) epi_step(a_c, r0 + r, 3, d_tile, false, false, r);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   auto lseg_epi = [&](auto a_c, auto nr_c, int r0, bool on, int d_tile, int bslot, bool zero) __attribute__((always_inline)) {
     constexpr int NR = decltype(nr_c)::value;
     if (NR > 0 && !kWoven) {
@@ -976,11 +995,17 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
     // fragments are then not live across the conversion (the 256x256 variants sit at the 256-VGPR limit), at the price of their
     // LDS latency once per such segment.
     constexpr bool kE01 = !kWoven && nr01_t::value > 0, kE23 = !kWoven && nr23_t::value > 0;
-    if (kE01) {
+    // hybrid store segments: mode 3 p3 (half 0 rows 0-1 of this tile); mode 1 p0 (half 0 rows 2-3 of the previous tile), p1 and
+    // p2 (half 1 of the previous tile)
+    constexpr bool kH1 = kHybrid && MODE == 1, kH3 = kHybrid && MODE >= 3;
+    using h2_t = std::integral_constant<int, 2>;
+    using hm_t = std::integral_constant<int, MA1 / 2>;
+    if (kE01 || kH1) {
       stage_scales(slot ^ 1, kt_1, ra_1, rb_1);
       stage_bias(ti_1 & 1, rb_1);
       stage_b1(sb1, oth);
-      lseg_epi(c1_t{}, nr01_t{}, 0, flag, d_tile, bslot, MX);
+      if (kH1) lseg_store(c0_t{}, h2_t{}, 2, flag, d_tile);
+      else lseg_epi(c1_t{}, nr01_t{}, 0, flag, d_tile, bslot, MX);
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) b0f[j] = frag(kOffB0, wc * 2, j);
@@ -1008,7 +1033,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
         }
       }
     }
-    if (!kE01) {
+    if (!(kE01 || kH1)) {
       stage_scales(slot ^ 1, kt_1, ra_1, rb_1);
       stage_bias(ti_1 & 1, rb_1);
       stage_b1(sb1, oth);
@@ -1023,13 +1048,14 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
     MI_PHASE_END();
     stamp();
     // ---- phase 1: C[0][*][1][*]
-    if (kE01) {
+    if (kE01 || kH1) {
       stage_a1(sa1, oth);
-      lseg_epi(c1_t{}, nr01_t{}, MA1 / 2, flag, d_tile, bslot, MX);
+      if (kH1) lseg_store(c1_t{}, hm_t{}, 0, flag, d_tile);
+      else lseg_epi(c1_t{}, nr01_t{}, MA1 / 2, flag, d_tile, bslot, MX);
     }
 #pragma unroll
     for (int j = 0; j < NB1; ++j) b1f[j] = frag(kOffB1, wc * NB1, j);
-    if (!kE01) stage_a1(sa1, oth);
+    if (!(kE01 || kH1)) stage_a1(sa1, oth);
     MI_WAIT_SYNC(MODE, flag, 1)
     stamp();
     mseg(c4_t{}, nb1_t{}, [&](int i, int j) __attribute__((always_inline)) {
@@ -1040,13 +1066,14 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
     MI_PHASE_END();
     stamp();
     // ---- phase 2: C[1][*][1][*]
-    if (kE23) {
+    if (kE23 || kH1) {
       stage_a0(sa2, cur);
-      lseg_epi(c0_t{}, nr23_t{}, 0, true, d_tile, bslot, MX);
+      if (kH1) lseg_store(c1_t{}, hm_t{}, MA1 / 2, flag, d_tile);
+      else lseg_epi(c0_t{}, nr23_t{}, 0, true, d_tile, bslot, MX);
     }
 #pragma unroll
     for (int i = 0; i < MA1; ++i) af[i] = frag(kOffA1, wr * MA1, i);
-    if (!kE23) stage_a0(sa2, cur);
+    if (!(kE23 || kH1)) stage_a0(sa2, cur);
     MI_WAIT_SYNC(MODE, flag, 2)
     stamp();
     mseg(ma1_t{}, nb1_t{}, [&](int i, int j) __attribute__((always_inline)) {
@@ -1058,6 +1085,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
     stamp();
     // ---- phase 3: C[1][*][0][*]
     stage_b0(sb2, cur);
+    if (kH3) lseg_store(c0_t{}, h2_t{}, 0, true, d_tile);
     lseg_epi(c0_t{}, nr23_t{}, 2, true, d_tile, bslot, MX);
     MI_WAIT_SYNC(MODE, flag, 3)
     stamp();
@@ -1172,7 +1200,13 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (my_tiles > 0) epi_rows(c1_t{}, 0, MA1, d_prev, (my_tiles - 1) & 1, false);  // row half 1 of the last tile
+    if (my_tiles > 0) {
+      if (kHybrid) {  // half 0 rows 2-3 of the last tile: converted in its last MFMA segment, not stored yet
+        epi_step(c0_t{}, 2, 3, d_prev, false, false, 0);
+        epi_step(c0_t{}, 3, 3, d_prev, false, false, 1);
+      }
+      epi_rows(c1_t{}, 0, MA1, d_prev, (my_tiles - 1) & 1, false);  // row half 1 of the last tile
+    }
     if (ABL == 9) {
       if (blockIdx.x == 0 && (wave & 3) == 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1325,7 +1359,7 @@ static int launch_p8(const uint8_t* a, const uint8_t* b, uint16_t* D, const floa
     case 2: MI_P8(MXv, BIASv, ABLv, 2, 2); break;                   \
     default: MI_P8(MXv, BIASv, ABLv, 2, 1); break;                  \
   }
-  if (algo == 46 || (algo >= 15 && algo <= 28)) {  // timing-only / diagnostic builds: E4M3 x E4M3 only (compile time)
+  if (algo == 46 || (algo >= 15 && algo <= 29)) {  // timing-only / diagnostic builds: E4M3 x E4M3 only (compile time)
     if constexpr (FA == 0 && FB == 0) {
       if (algo == 46) {  // A/B baseline: block epilogue after each tile (the round-1 form)
         switch (cfg) {
@@ -1346,6 +1380,9 @@ static int launch_p8(const uint8_t* a, const uint8_t* b, uint16_t* D, const floa
         MI_P8_CFG(false, false, 9)
       } else if (algo == 21) {  // `bias` is a u64[4 * grid] stamp buffer (cycles, 100 MHz ticks, steps, XCC id)
         MI_P8_CFG(false, false, 8)
+      } else if (algo == 29) {  // conversion woven into the MFMA segments, stores one load segment later (timing A/B; K >= 512)
+        if (K < 512) { set_error("mi_gemm: algo 29 needs K >= 512"); return MI_ERR_SHAPE; }
+        MI_P8_CFG(false, false, 16)
       } else if (algo == 28) {  // no epilogue at all (timing only): what conversion + stores cost together
         MI_P8_CFG(false, false, 15)
       } else if (algo == 27) {  // epilogue woven into the MFMA segments (timing A/B)
@@ -1393,7 +1430,7 @@ static int launch_fmt(const void* A, const void* B, void* D, const float* sa_inv
     int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
     hipLaunchKernelGGL((gemm_256_8ph<FA, FB, OUT>), dim3(tiles_m * tiles_n), dim3(512), 0, st, a, b, D, sa_inv, sb_inv,
                        bp, (int)M, (int)N, (int)K, lda, ldb, ldd, tiles_m, tiles_n);
-  } else if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 28) || (algo >= 40 && algo <= 46)) {
+  } else if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 29) || (algo >= 40 && algo <= 46)) {
     return launch_p8<FA, FB>(a, b, (uint16_t*)D, sa_inv, sb_inv, (const uint8_t*)SA, (const uint8_t*)SB, bp, M, N, K, lda, ldb, ldd,
                              algo, mx, st);
   } else if (algo == 13 && !mx) {
@@ -1453,7 +1490,7 @@ static int pick_algo(int algo, int64_t M, int64_t N, int64_t K, int64_t lda, int
   const bool p8_ok = (M % 256 == 0 || M % 192 == 0) && (N % 256 == 0 || N % 192 == 0) && M > 0 && N > 0 && K > 0 &&
                      (K % (2 * BK) == 0) && out == 0 && M * lda < (1LL << 31) && N * ldb < (1LL << 31) &&
                      M * ldd * 2 < (1LL << 31);
-  if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 28) || (algo >= 40 && algo <= 46)) {
+  if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 29) || (algo >= 40 && algo <= 46)) {
     if (!p8_ok) {
       set_error("%s: algo %d needs M,N %% 256 (or 192) == 0, K %% 256 == 0, bf16 output, operands < 2 GiB", who, algo);
       return MI_ERR_SHAPE;
