@@ -767,6 +767,25 @@ def test_persistent_gemm_bitwise_reproducible_under_load(ops, dev, mx, shape):
         assert torch.equal(run(), ref)
 
 
+@pytest.mark.parametrize("shape", [(2048, 4096, 512), (8192, 3072, 1024), (3072, 3072, 768), (768, 3072, 1280)])
+@pytest.mark.parametrize("algo", [27, 29, 46])
+def test_epilogue_placement_builds_are_bitwise_the_default(ops, dev, shape, algo):
+    """The timing builds that move the epilogue (27: woven into the MFMA segments, 29: conversion woven / stores one load segment
+    later, 46: block epilogue after each tile) compute the same fp32 sums in the same order as the default placement: any
+    difference means a quadrant was converted after its registers were reused, or a counted vmcnt wait let a store's data or
+    an LDS tile be overwritten early.  Shapes: 2 - 8 tiles per workgroup on all four tile shapes, K = 512 .. 1280."""
+    M, N, K = shape
+    g = torch.Generator(device=dev).manual_seed(11)
+    a = torch.randint(0, 256, (M, K), generator=g, device=dev, dtype=torch.uint8)
+    b = torch.randint(0, 256, (N, K), generator=g, device=dev, dtype=torch.uint8)
+    for t in (a, b):
+        t[(t & 0x7F) >= 0x78] &= 0x3F
+    sa, sb = torch.full((1,), 0.37, device=dev), torch.full((1,), 1.9, device=dev)
+    ref = ops.gemm_fp8(a, b, sa, sb, 0, 0, algo=4)
+    for _ in range(3):
+        assert torch.equal(ops.gemm_fp8(a, b, sa, sb, 0, 0, algo=algo), ref)
+
+
 @pytest.mark.parametrize("fmt", [O.E4M3, O.E5M2])
 def test_mxfp8_quantize_row_blocks_and_colsum(ops, dev, fmt):
     """mi_mxfp8_quantize_ex: parts quantised into their row-blocks of a larger operand == quantising the concatenation
