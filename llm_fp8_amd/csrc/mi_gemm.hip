@@ -1234,21 +1234,25 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
 // cfg: 0 = 256x256, 1 = 256x192, 2 = 192x256, 3 = 192x192.
 static int pick_tile_cfg(int64_t M, int64_t N, int64_t K) {
   static const int bm[4] = {256, 256, 192, 192}, bn[4] = {256, 192, 256, 192};
-  // measured relative efficiency of the shorter phases; 192-COLUMN tiles (NB1 == 1) also store half lines (64 + 32 B per row),
-  // 192-ROW tiles keep whole 128-byte lines: 6144x6144x4096 runs 126.5 us as 256x192 and 118.8 us as 192x256 tiles
-  static const double eff[4] = {1.0, 0.88, 0.92, 0.80};
+  // measured relative efficiency of the shorter phases.  192-COLUMN tiles (NB1 == 1) store half lines (a wave's 48 columns = 64
+  // + 32 B per row), 192-ROW tiles keep whole 128-byte lines: 6144x6144x4096 runs 126.5 us as 256x192 and 118.8 us as 192x256
+  // tiles.  And half-line stores pay extra when the output lines are COLD, which in a training step they always are (the
+  // output is a fresh 50-MB tensor; a benchmark loop rewrites the same one): 8192x3072x3072 as 256x192 tiles takes 74.9 us into
+  // a warm output and 90.5 us rotating over 12 outputs, 256x256 tiles 78.0 / 77.4 us (tools/bench_kernels.py --which rotout).
+  // The penalty is per output byte, i.e. ~1/K of the tile time: eff = 0.88 / (1 + 1150 / K) fits K = 3072 .. 16384.
+  const double cold = 1.0 + 1150.0 / (double)(K > 0 ? K : 1);
+  const double eff[4] = {1.0, 0.88 / cold, 0.92, 0.80 / cold};
   const int ncu = num_cus();
   int best = -1;
   double best_cost = 0;
   // Measured on MI355X with interleaved A/B timing (tools/bench_kernels.py --which tiles; back-to-back timing is biased by
   // clock drift): 8192x3072xK as 512 tiles of 256x192 beats 384 tiles of 256x256 by 5 % (K 3072) to 9 % (K 16384).
-  (void)K;
   for (int c = 0; c < 4; ++c) {
     if (M % bm[c] || N % bn[c]) continue;
     const int64_t tiles = (M / bm[c]) * (N / bn[c]);
     const int64_t rounds = (tiles + ncu - 1) / ncu;
     const double cost = (double)rounds * bm[c] * bn[c] / eff[c];
-    if (best < 0 || cost < best_cost * 0.97) {  // prefer the larger tile unless the gain is > 3 %
+    if (best < 0 || cost < best_cost * 0.98) {  // prefer the larger tile unless the gain is > 2 % (in the step fc2 fprop, K = 8192: 170 us as 256x192, 178 us as 256x256 tiles)
       best = c;
       best_cost = cost;
     }

@@ -141,6 +141,20 @@ def main():
             fns["half24"] = (lambda: ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=24))
             res = time_interleaved(fns, rounds=8, inner=6)
             print(f"stagger {m}x{n}x{k}: " + "  ".join(f"{al}: {t*1e6:7.1f} us {2.0*m*n*k/t/1e12:6.0f} TF" for al, t in res.items()), flush=True)
+    if "rotout" in args.which:  # do the half-line stores of the 192-column tiles pay extra when the output lines are cold?
+        for (m, n, k) in ((8192, 3072, 3072), (8192, 3072, 8192), (8192, 5120, 3072)):
+            a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
+            outs = [torch.empty((m, n), dtype=torch.bfloat16, device=dev) for _ in range(12)]  # 12 x 50-84 MB > the 256-MiB Infinity Cache
+            cnt = [0]
+            def mk(al, rot):
+                def f():
+                    cnt[0] += 1
+                    ops.gemm_fp8(a, b, one, one, 0, 0, out=outs[cnt[0] % 12 if rot else 0], algo=al)
+                return f
+            fns = {f"{name}{'_rot' if rot else ''}": mk(al, rot) for name, al in (("256x256", 40), ("256x192", 41)) for rot in (False, True)
+                   if not (al == 41 and n % 192)}
+            res = time_interleaved(fns, rounds=8, inner=6)
+            print(f"rotout {m}x{n}x{k}: " + "  ".join(f"{al}: {t*1e6:7.1f} us" for al, t in res.items()), flush=True)
     if "storepol" in args.which:  # epilogue store cache policy: sc1 (default) / plain / nt / sc1+nt / no stores, interleaved A/B
         shapes = [(8192, 8192, 2048), (8192, 16384, 3072), (8192, 3072, 16384), (16384, 3072, 8192), (8192, 3072, 8192), (8192, 8192, 3072), (8192, 5120, 3072), (8192, 3072, 3072),
                   (8192, 128256, 3072), (128256, 3072, 8192), (8192, 28672, 4096), (6144, 28672, 4096)]
