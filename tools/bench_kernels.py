@@ -155,6 +155,31 @@ def main():
                    if not (al == 41 and n % 192)}
             res = time_interleaved(fns, rounds=8, inner=6)
             print(f"rotout {m}x{n}x{k}: " + "  ".join(f"{al}: {t*1e6:7.1f} us" for al, t in res.items()), flush=True)
+    if "rotcast" in args.which:  # do the 64-byte row segments of the cast kernels pay for cold output lines, as the GEMM's half lines do?
+        scale, amax = torch.ones(1, device=dev), torch.zeros(1, device=dev)
+        for (r, c) in ((8192, 3072), (8192, 8192)):
+            xs = [torch.randn(r, c, device=dev, dtype=torch.bfloat16) for _ in range(8)]
+            ys = [torch.empty((r, c), dtype=torch.uint8, device=dev) for _ in range(16)]
+            yts = [torch.empty((c, r), dtype=torch.uint8, device=dev) for _ in range(16)]
+            cnt = [0]
+            def mk(rot_in, rot_out):
+                def f():
+                    cnt[0] += 1
+                    ops.cast_amax(xs[cnt[0] % 8 if rot_in else 0], scale, amax, 0, y=ys[cnt[0] % 16 if rot_out else 0], yT=yts[cnt[0] % 16 if rot_out else 0])
+                return f
+            fns = {"warm": mk(False, False), "rot_in": mk(True, False), "rot_out": mk(False, True), "rot_both": mk(True, True)}
+            res = time_interleaved(fns, rounds=8, inner=8)
+            nb = r * c * 4
+            print(f"rotcast cast_amax {r}x{c}: " + "  ".join(f"{k_}: {t*1e6:6.1f} us {nb/t/1e12:5.2f} TB/s" for k_, t in res.items()), flush=True)
+        h_in = [torch.randn(8192, 16384, device=dev, dtype=torch.bfloat16) for _ in range(4)]
+        cnt = [0]
+        def sw(rot):
+            def f():
+                cnt[0] += 1
+                ops.swiglu_cast(h_in[cnt[0] % 4 if rot else 0], scale, amax, 0)
+            return f
+        res = time_interleaved({"warm_in": sw(False), "rot_in": sw(True)}, rounds=8, inner=6)
+        print("rotcast swiglu_cast 8192x8192 (outputs are fresh allocations either way): " + "  ".join(f"{k_}: {t*1e6:6.1f} us" for k_, t in res.items()), flush=True)
     if "storepol" in args.which:  # epilogue store cache policy: sc1 (default) / plain / nt / sc1+nt / no stores, interleaved A/B
         shapes = [(8192, 8192, 2048), (8192, 16384, 3072), (8192, 3072, 16384), (16384, 3072, 8192), (8192, 3072, 8192), (8192, 8192, 3072), (8192, 5120, 3072), (8192, 3072, 3072),
                   (8192, 128256, 3072), (128256, 3072, 8192), (8192, 28672, 4096), (6144, 28672, 4096)]
