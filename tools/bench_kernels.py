@@ -171,6 +171,20 @@ def main():
             res = time_interleaved(fns, rounds=8, inner=8)
             nb = r * c * 4
             print(f"rotcast cast_amax {r}x{c}: " + "  ".join(f"{k_}: {t*1e6:6.1f} us {nb/t/1e12:5.2f} TB/s" for k_, t in res.items()), flush=True)
+        for (r, c) in ((8192, 8192), (8192, 16384)):  # which copy pays: the row-major one or the transposed one?
+            x0 = torch.randn(r, c, device=dev, dtype=torch.bfloat16)
+            ys = [torch.empty((r, c), dtype=torch.uint8, device=dev) for _ in range(16)]
+            yts = [torch.empty((c, r), dtype=torch.uint8, device=dev) for _ in range(16)]
+            cnt = [0]
+            def mk1(want_y, want_t, rot):
+                def f():
+                    cnt[0] += 1
+                    i = cnt[0] % 16 if rot else 0
+                    ops.cast_amax(x0, scale, amax, 0, want_y=want_y, want_t=want_t, y=ys[i] if want_y else None, yT=yts[i] if want_t else None)
+                return f
+            fns = {"y_warm": mk1(True, False, False), "y_rot": mk1(True, False, True), "yT_warm": mk1(False, True, False), "yT_rot": mk1(False, True, True)}
+            res = time_interleaved(fns, rounds=8, inner=8)
+            print(f"rotcast cast_amax {r}x{c} one copy: " + "  ".join(f"{k_}: {t*1e6:6.1f} us" for k_, t in res.items()), flush=True)
         h_in = [torch.randn(8192, 16384, device=dev, dtype=torch.bfloat16) for _ in range(4)]
         cnt = [0]
         def sw(rot):
