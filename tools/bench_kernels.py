@@ -194,6 +194,24 @@ def main():
             return f
         res = time_interleaved({"warm_in": sw(False), "rot_in": sw(True)}, rounds=8, inner=6)
         print("rotcast swiglu_cast 8192x8192 (outputs are fresh allocations either way): " + "  ".join(f"{k_}: {t*1e6:6.1f} us" for k_, t in res.items()), flush=True)
+    if "mlpchunk" in args.which:  # does an M-chunked fc1 -> SwiGLU keep the bf16 fc1 output in the 256-MiB Infinity Cache?
+        scale, amax = torch.ones(1, device=dev), torch.zeros(1, device=dev)
+        M, F2, K = 8192, 16384, 3072
+        a, b = rand_fp8((M, K), dev, g), rand_fp8((F2, K), dev, g)
+        bias = torch.zeros(F2, device=dev, dtype=torch.bfloat16)
+        hs = [torch.empty((M, F2), dtype=torch.bfloat16, device=dev) for _ in range(6)]  # rotate: 6 x 268 MB
+        cnt = [0]
+        def run(chunks):
+            def f():
+                cnt[0] += 1
+                h = hs[cnt[0] % 6]
+                mc = M // chunks
+                for c in range(chunks):
+                    ops.gemm_fp8(a[c * mc:(c + 1) * mc], b, one, one, 0, 0, bias=bias, out=h[c * mc:(c + 1) * mc])
+                    ops.swiglu_cast(h[c * mc:(c + 1) * mc], scale, amax, 0)
+            return f
+        res = time_interleaved({"1 chunk": run(1), "2 chunks": run(2), "4 chunks": run(4)}, rounds=8, inner=4)
+        print("mlpchunk fc1 fprop + swiglu_cast, 8192 x 16384 x 3072: " + "  ".join(f"{k_}: {t*1e6:7.1f} us" for k_, t in res.items()), flush=True)
     if "storepol" in args.which:  # epilogue store cache policy: sc1 (default) / plain / nt / sc1+nt / no stores, interleaved A/B
         shapes = [(8192, 8192, 2048), (8192, 16384, 3072), (8192, 3072, 16384), (16384, 3072, 8192), (8192, 3072, 8192), (8192, 8192, 3072), (8192, 5120, 3072), (8192, 3072, 3072),
                   (8192, 128256, 3072), (128256, 3072, 8192), (8192, 28672, 4096), (6144, 28672, 4096)]
