@@ -53,7 +53,7 @@ extern "C" {
  * mi_abi_version() returns the value the library was built with; a binding compares it with the header it was written
  * against (llm_fp8_amd/_lib.py does at load time).
  *   1  round 1 (the surface of SURVEY.md 8b + fused neighbours)
- *   2  round 2: mi_gemm_fp8 algo values 20-29, 46 (diagnostic builds), mi_adamw_cast_bf16_multi, mi_transpose_u8,
+ *   2  round 2: mi_gemm_fp8 algo values 20-30, 46 (diagnostic builds), mi_adamw_cast_bf16_multi, mi_transpose_u8,
  *      mi_gemm_fp8_grouped
  */
 #define MI_ABI_VERSION 2
@@ -119,7 +119,7 @@ int mi_scale_update(float* amax_history, float* scale, float* scale_inv, const f
  * epilogue stores, 16 start stagger (env MI_GEMM_STAGGER), 17 plain write-back stores, 18 / 19 MX scale-path ablations,
  * 20 every tile streams tile (0,0)'s panels (L2-perfect), 21 in-kernel clock stamps (`bias_bf16` = u64[4 * grid]),
  * 22 per-phase stamps of workgroup 0 (`bias_bf16` = u64[2048]), 24 half-line stores, 25 nt stores, 26 sc1+nt stores,
- * 27 epilogue woven into the MFMA segments, 28 no epilogue at all, 29 conversion woven / stores one load segment later (K >= 512), 46 block epilogue after each tile (the round-1 form).  16 / 21 / 22 honour
+ * 27 epilogue woven into the MFMA segments, 28 no epilogue at all, 29 conversion woven / stores one load segment later (K >= 512), 30 odd tiles walk K downwards, 46 block epilogue after each tile (the round-1 form).  16 / 21 / 22 honour
  * env MI_GEMM_GRID (fewer workgroups).
  */
 int mi_gemm_fp8(const void* A, const void* B, void* D, const float* sa_inv, const float* sb_inv,

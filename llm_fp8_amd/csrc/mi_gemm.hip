@@ -630,6 +630,9 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   ti_2 = ti_1; kt_2 = kt_1; oa_2 = oa_1; ob_2 = ob_1; ra_2 = ra_1; rb_2 = rb_1;
   advance(ti_2, kt_2, oa_2, ob_2, ra_2, rb_2, 2);
 
+  // ABL 17 (algo 30, timing build): odd tiles walk K downwards ("serpentine"), so that a tile starts on the K window its
+  // predecessor on this CU -- and the other CUs of the XCD, which share its A panels across rounds -- ended on
+  auto keff = [&](int ti, int kt) -> int { return (ABL == 17 && (ti & 1)) ? nk - 1 - kt : kt; };
   uint8_t* const buf0 = lds;
   uint8_t* const buf1 = lds + kBufBytes;
   // prologue: step 0 complete, (step 1: A0, B0) in flight
@@ -640,8 +643,8 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   stage_b0(ob_0 + kb0, buf0);
   stage_b1(ob_0 + kb0, buf0);
   stage_a1(oa_0 + kb0, buf0);
-  stage_a0(oa_1 + kt_1 * BK, buf1);
-  stage_b0(ob_1 + kt_1 * BK, buf1);
+  stage_a0(oa_1 + keff(ti_1, kt_1) * BK, buf1);
+  stage_b0(ob_1 + keff(ti_1, kt_1) * BK, buf1);
   if (!SK && sk_U > 0) {
     // Start stagger (sk_U = units of 512 cycles per class, 0 = off): the CUs of an XCD start in 4 classes a few microseconds
     // apart, so their epilogue store bursts (128 KiB per CU and tile, all CUs at once = 32 MiB against ~6 TB/s of store
@@ -974,8 +977,8 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
     using wv23_t = std::integral_constant<int, (kWoven ? nr23_t::value : 0)>;
     using ma1_t = std::integral_constant<int, MA1>;
     using nb1_t = std::integral_constant<int, NB1>;
-    const int sa1 = oa_1 + kt_1 * BK, sb1 = ob_1 + kt_1 * BK;
-    const int sa2 = oa_2 + kt_2 * BK, sb2 = ob_2 + kt_2 * BK;
+    const int sa1 = oa_1 + keff(ti_1, kt_1) * BK, sb1 = ob_1 + keff(ti_1, kt_1) * BK;
+    const int sa2 = oa_2 + keff(ti_2, kt_2) * BK, sb2 = ob_2 + keff(ti_2, kt_2) * BK;
     // Fragment reads: explicit per-lane bases (fa_* / fb_*, see their definition) + immediate offsets -- no address VALU in the
     // load segments (8 v_add per K-tile there cost 2 %: every VALU instruction delays the segment's LDS-DMA issue and barrier)
     // and no compiler-hoisted base per (operand half, buffer) (ten VGPRs, some spilled and reloaded behind `s_waitcnt vmcnt(0)`).
@@ -1363,7 +1366,7 @@ static int launch_p8(const uint8_t* a, const uint8_t* b, uint16_t* D, const floa
     case 2: MI_P8(MXv, BIASv, ABLv, 2, 2); break;                   \
     default: MI_P8(MXv, BIASv, ABLv, 2, 1); break;                  \
   }
-  if (algo == 46 || (algo >= 15 && algo <= 29)) {  // timing-only / diagnostic builds: E4M3 x E4M3 only (compile time)
+  if (algo == 46 || (algo >= 15 && algo <= 30)) {  // timing-only / diagnostic builds: E4M3 x E4M3 only (compile time)
     if constexpr (FA == 0 && FB == 0) {
       if (algo == 46) {  // A/B baseline: block epilogue after each tile (the round-1 form)
         switch (cfg) {
@@ -1384,6 +1387,8 @@ static int launch_p8(const uint8_t* a, const uint8_t* b, uint16_t* D, const floa
         MI_P8_CFG(false, false, 9)
       } else if (algo == 21) {  // `bias` is a u64[4 * grid] stamp buffer (cycles, 100 MHz ticks, steps, XCC id)
         MI_P8_CFG(false, false, 8)
+      } else if (algo == 30) {  // odd tiles walk K downwards (L2 reuse across tile boundaries; fp32 summation order differs per tile parity)
+        MI_P8_CFG(false, false, 17)
       } else if (algo == 29) {  // conversion woven into the MFMA segments, stores one load segment later (timing A/B; K >= 512)
         if (K < 512) { set_error("mi_gemm: algo 29 needs K >= 512"); return MI_ERR_SHAPE; }
         MI_P8_CFG(false, false, 16)
@@ -1434,7 +1439,7 @@ static int launch_fmt(const void* A, const void* B, void* D, const float* sa_inv
     int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
     hipLaunchKernelGGL((gemm_256_8ph<FA, FB, OUT>), dim3(tiles_m * tiles_n), dim3(512), 0, st, a, b, D, sa_inv, sb_inv,
                        bp, (int)M, (int)N, (int)K, lda, ldb, ldd, tiles_m, tiles_n);
-  } else if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 29) || (algo >= 40 && algo <= 46)) {
+  } else if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 30) || (algo >= 40 && algo <= 46)) {
     return launch_p8<FA, FB>(a, b, (uint16_t*)D, sa_inv, sb_inv, (const uint8_t*)SA, (const uint8_t*)SB, bp, M, N, K, lda, ldb, ldd,
                              algo, mx, st);
   } else if (algo == 13 && !mx) {
@@ -1494,7 +1499,7 @@ static int pick_algo(int algo, int64_t M, int64_t N, int64_t K, int64_t lda, int
   const bool p8_ok = (M % 256 == 0 || M % 192 == 0) && (N % 256 == 0 || N % 192 == 0) && M > 0 && N > 0 && K > 0 &&
                      (K % (2 * BK) == 0) && out == 0 && M * lda < (1LL << 31) && N * ldb < (1LL << 31) &&
                      M * ldd * 2 < (1LL << 31);
-  if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 29) || (algo >= 40 && algo <= 46)) {
+  if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 30) || (algo >= 40 && algo <= 46)) {
     if (!p8_ok) {
       set_error("%s: algo %d needs M,N %% 256 (or 192) == 0, K %% 256 == 0, bf16 output, operands < 2 GiB", who, algo);
       return MI_ERR_SHAPE;

@@ -219,7 +219,7 @@ def main():
             a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
             out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
             fns = {name: (lambda al=al: ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=al))
-                   for name, al in (("sc1", 4), ("hybrid", 29), ("plain", 17), ("nt", 25), ("sc1nt", 26), ("nostore", 15), ("noepi", 28), ("block46", 46))}
+                   for name, al in (("sc1", 4), ("serp", 30), ("hybrid", 29), ("plain", 17), ("nt", 25), ("sc1nt", 26), ("nostore", 15), ("noepi", 28), ("block46", 46))}
             ref = ops.gemm_fp8(a, b, one, one, 0, 0, algo=4)
             hyb = ops.gemm_fp8(a, b, one, one, 0, 0, algo=29)
             assert torch.equal(ref, hyb), f"algo 29 differs from algo 4 on {m}x{n}x{k}: {(ref.float() - hyb.float()).abs().max().item()}"
