@@ -891,7 +891,6 @@ __global__ __launch_bounds__(512, 2) void gemm_256_p8(const uint8_t* __restrict_
   using c2_t = std::integral_constant<int, 2>;
   using c3_t = std::integral_constant<int, 3>;
   using c4_t = std::integral_constant<int, 4>;
-  using c8_t = std::integral_constant<int, 8>;
   // the fragment rows [r0, r0 + nr) of half a, back to back (after the tile walk; stream-K / block-epilogue path)
   auto epi_rows = [&](auto a_c, int r0, int nr, int d_tile, int bslot, bool zero) __attribute__((always_inline)) {
     epi_begin(bslot);
