@@ -18,6 +18,6 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $out/under_rocprof.log 2>&1 || { echo "rocprof run FAILED"; tail -5 $out/under_rocprof.log; exit 1; }
 grep "^{" $out/under_rocprof.log > $out/${tag}_bench_under_rocprof.json
 cp $out/prof/*/*_kernel_stats.csv $out/${tag}_bench_kernel_stats.csv
-# the --stats table sums the whole process (initialisation, warm-up, grouped-GEMM autotune launches): cut the steady steps out of the trace
+# the --stats table sums the whole process (initialisation, warm-up, the clock probe's and the grouped-GEMM autotune's launches): cut the steady steps out of the trace
 python3 $GRAFT_REPO_ROOT/tools/trace_steady_stats.py $out/prof/*/*_kernel_trace.csv $out/${tag}_bench_kernel_stats_steady.csv 4
 echo done

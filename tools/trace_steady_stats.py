@@ -3,8 +3,8 @@
     python tools/trace_steady_stats.py <..._kernel_trace.csv> <out.csv> [steps]
 
 rocprofv3's own --stats table sums the whole process: model initialisation, the warm-up steps and the one-off launches of
-the grouped-GEMM autotune (ops.grouped_gemm_autotune times every candidate a few times at the first backward of each shape
-set) -- thousands of extra GEMM launches that belong to no step.  This tool cuts the trace at the optimiser launches (one
+bench.py's in-kernel clock probe (2 s of back-to-back GEMMs) and of the grouped-GEMM autotune -- thousands of extra GEMM
+launches that belong to no step.  This tool cuts the trace at the optimiser launches (one
 `adamw*_multi_kernel` per step; the last launch of a step) and keeps the LAST `steps` steps.  Columns as rocprofv3's
 kernel_stats.csv plus CallsPerStep / MsPerStep."""
 import csv, sys
