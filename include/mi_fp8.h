@@ -55,8 +55,9 @@ extern "C" {
  *   1  round 1 (the surface of SURVEY.md 8b + fused neighbours)
  *   2  round 2: mi_gemm_fp8 algo values 20-30, 46 (diagnostic builds), mi_adamw_cast_bf16_multi, mi_transpose_u8,
  *      mi_gemm_fp8_grouped
+ *   3  round 2: mi_adamw_mxcast_bf16_multi
  */
-#define MI_ABI_VERSION 2
+#define MI_ABI_VERSION 3
 int mi_abi_version(void);
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* mi_last_error(void);
@@ -317,6 +318,18 @@ int mi_adamw_bf16_multi(const int64_t* table, int n_tensors, const int32_t* chun
 int mi_adamw_cast_bf16_multi(const int64_t* table, int n_tensors, const int32_t* chunks, int n_chunks, int chunk_elems,
                              const float* grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay,
                              int64_t step, void* stream);
+/*
+ * The MXFP8 form of mi_adamw_cast_bf16_multi (ABI 3): block scaling has no state, so the copies the next forward would
+ * quantise (K7 on every weight: row-wise blocks for fprop, column-wise blocks stored transposed for dgrad) leave with the update.
+ * table: int64 [12, n_tensors]: rows 0-5 as above (cols > 0: a [numel / cols, cols] weight walked in 128 x 128 tiles), then
+ *   6 y_row (fp8 e4m3 [rows, cols]), 7 s_row (E8M0 [cols/32, ldr]), 8 y_colT (fp8 [cols, ldr]), 9 s_colT (E8M0 [rows/32, cols]),
+ *   10 ldr (row count of the operand the tensor is a row-block of: query | key | value form one operand), 11 unused.
+ * Rows 6-9 point at the tensor's first row inside the operand's buffers.  Bitwise the bytes of mi_mxfp8_quantize(_ex) on the
+ * updated, bf16-rounded weight.  rows and cols multiples of 32; the row offset of a part a multiple of 32.
+ */
+int mi_adamw_mxcast_bf16_multi(const int64_t* table, int n_tensors, const int32_t* chunks, int n_chunks, int chunk_elems,
+                               const float* grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay,
+                               int64_t step, void* stream);
 
 /*
  * Embedding weight gradient added in place: grad[id, :] += alpha * sum_{tokens t with ids[t] == id} dY[t, :]   (bf16, fp32

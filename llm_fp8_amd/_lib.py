@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("LLM_FP8_AMD_LIB") or os.path.join(_HERE, "libmi_fp8.s
 
 MI_FMT_E4M3 = 0
 MI_FMT_E5M2 = 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c_i64 = ctypes.c_int64
 _c_int = ctypes.c_int
@@ -53,6 +53,8 @@ SIGNATURES = {
                             ctypes.c_float, _c_i64, _p],
     "mi_adamw_cast_bf16_multi": [_p, _c_int, _p, _c_int, _c_int, _p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, _c_i64, _p],
+    "mi_adamw_mxcast_bf16_multi": [_p, _c_int, _p, _c_int, _c_int, _p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                   ctypes.c_float, _c_i64, _p],
     "mi_embedding_grad_add": [_p, _p, _p, _p, _c_i64, _c_i64, _c_i64, ctypes.c_float, _c_i64, _p],
     "mi_adamw_bf16": [_p, _p, _p, _p, _c_i64, _p, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                       ctypes.c_float, _c_i64, _p],

@@ -113,6 +113,23 @@ __device__ __forceinline__ void transpose4x4(u32 r0, u32 r1, u32 r2, u32 r3, u32
   c3 = bperm(t23h, t01h, 0x07060302u);
 }
 
+// E8M0 biased exponent of (amax * 1/fp8_max), rounded up to the next power of two.
+__device__ __forceinline__ u32 e8m0_roundup(float val) {
+  u32 u = __float_as_uint(val);
+  u32 e = (u >> 23) & 0xFFu, man = u & 0x7FFFFFu;
+  if (man > 0 && e != 0xFEu && !(e == 0 && man <= 0x400000u)) ++e;
+  if (val != val) e = 0xFFu;
+  else if (isinf(val)) e = 0xFEu;
+  else if (val == 0.0f) e = 0u;
+  return e;
+}
+// 2^(127 - e) as fp32 (exact; subnormal for e = 254, NaN for e = 255)
+__device__ __forceinline__ float e8m0_inv(u32 e) {
+  if (e == 0xFFu) return __uint_as_float(0x7FC00000u);
+  if (e == 0xFEu) return __uint_as_float(0x00400000u);
+  return __uint_as_float((254u - e) << 23);
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));

@@ -357,6 +357,199 @@ __global__ __launch_bounds__(256) void adamw_cast_multi_kernel(const int64_t* __
   }
 }
 
+// AdamW + MXFP8 weight quantisation in one pass: the MXFP8 form of the weight-cast hand-off.  Block scaling has no state -- the
+// E8M0 scale of a 32-element block comes from the block itself -- so the copies the NEXT forward needs (row-wise blocks for
+// fprop, column-wise blocks, stored transposed, for dgrad) can be emitted as soon as the weight is updated.  Same tile walk as
+// adamw_cast_multi_kernel (128 x 128 tile per workgroup, 8 x 8 block per lane); the quantisation of the ROUNDED bf16 weight is
+// mxfp8_quant_kernel's, operation for operation (bitwise the bytes mi_mxfp8_quantize would produce from the updated weight).
+// Table rows (int64 each, T columns):
+//   0 p  1 g  2 exp_avg  3 exp_avg_sq  4 numel  5 cols (0 = no sink: flat path)  6 y_row  7 s_row  8 y_colT  9 s_colT
+//   10 ldr (rows of the whole operand the tensor is a row-block of)  11 unused
+// y_row / s_row / y_colT / s_colT point at the tensor's first row inside the operand's buffers: y_row [rows, cols],
+// s_row [cols/32, ldr], y_colT [cols, ldr], s_colT [rows/32, cols].
+__global__ __launch_bounds__(256) void adamw_mxcast_multi_kernel(const int64_t* __restrict__ tab, int T, const ChunkRef* __restrict__ chunks,
+                                                                 int chunk_elems, const float* __restrict__ grad_scale, AdamArgs a) {
+  const ChunkRef cr = chunks[blockIdx.x];
+  uint16_t* p = reinterpret_cast<uint16_t*>(tab[cr.tensor]);
+  const uint16_t* g = reinterpret_cast<const uint16_t*>(tab[(int64_t)1 * T + cr.tensor]);
+  uint16_t* m = reinterpret_cast<uint16_t*>(tab[(int64_t)2 * T + cr.tensor]);
+  uint16_t* v = reinterpret_cast<uint16_t*>(tab[(int64_t)3 * T + cr.tensor]);
+  const int64_t n = tab[(int64_t)4 * T + cr.tensor];
+  const int64_t cols = tab[(int64_t)5 * T + cr.tensor];
+  const float gs = grad_scale ? *grad_scale : 1.0f;
+  const int tid = threadIdx.x;
+  if (cols == 0) {  // flat chunk (same arithmetic and traversal as adamw_multi_kernel)
+    const int64_t lo = (int64_t)cr.chunk * chunk_elems, hi = min(n, lo + chunk_elems);
+    const bool aligned = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
+    int64_t done = lo;
+    if (aligned) {
+      const int64_t v0 = lo >> 3, v1 = hi >> 3;
+      for (int64_t i = v0 + tid; i < v1; i += 256) {
+        v4i pv = reinterpret_cast<const v4i*>(p)[i];
+        const v4i gv = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(g) + i);
+        v4i mv = reinterpret_cast<const v4i*>(m)[i];
+        v4i vv = reinterpret_cast<const v4i*>(v)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float pl = __uint_as_float((u32)pv[j] << 16), ph = __uint_as_float((u32)pv[j] & 0xFFFF0000u);
+          const float gl = gs * __uint_as_float((u32)gv[j] << 16), gh = gs * __uint_as_float((u32)gv[j] & 0xFFFF0000u);
+          float ml = __uint_as_float((u32)mv[j] << 16), mh = __uint_as_float((u32)mv[j] & 0xFFFF0000u);
+          float vl = __uint_as_float((u32)vv[j] << 16), vh = __uint_as_float((u32)vv[j] & 0xFFFF0000u);
+          adam_one(pl, gl, ml, vl, a);
+          adam_one(ph, gh, mh, vh, a);
+          pv[j] = (int)pack_bf16x2(pl, ph);
+          mv[j] = (int)pack_bf16x2(ml, mh);
+          vv[j] = (int)pack_bf16x2(vl, vh);
+        }
+        reinterpret_cast<v4i*>(p)[i] = pv;
+        reinterpret_cast<v4i*>(m)[i] = mv;
+        reinterpret_cast<v4i*>(v)[i] = vv;
+      }
+      done = v1 << 3;
+    }
+    for (int64_t k = done + tid; k < hi; k += 256) {
+      float pf = bf16_bits_to_float(p[k]), mf = bf16_bits_to_float(m[k]), vf = bf16_bits_to_float(v[k]);
+      adam_one(pf, gs * bf16_bits_to_float(g[k]), mf, vf, a);
+      p[k] = (uint16_t)float_to_bf16_bits(pf);
+      m[k] = (uint16_t)float_to_bf16_bits(mf);
+      v[k] = (uint16_t)float_to_bf16_bits(vf);
+    }
+    return;
+  }
+  uint8_t* y_row = reinterpret_cast<uint8_t*>(tab[(int64_t)6 * T + cr.tensor]);
+  uint8_t* s_row = reinterpret_cast<uint8_t*>(tab[(int64_t)7 * T + cr.tensor]);
+  uint8_t* y_colT = reinterpret_cast<uint8_t*>(tab[(int64_t)8 * T + cr.tensor]);
+  uint8_t* s_colT = reinterpret_cast<uint8_t*>(tab[(int64_t)9 * T + cr.tensor]);
+  const int64_t ldr = tab[(int64_t)10 * T + cr.tensor];
+  const int64_t rows = n / cols;
+  const int tiles_c = (int)((cols + 127) >> 7);
+  const int lane = tid & 63, wave = tid >> 6;
+  const int tile_r = cr.chunk / tiles_c, tile_c = cr.chunk % tiles_c;
+  const int64_t r0 = (int64_t)tile_r * 128 + (wave >> 1) * 64 + (lane >> 3) * 8;
+  const int64_t c0 = (int64_t)tile_c * 128 + (wave & 1) * 64 + (lane & 7) * 8;
+  const bool active = r0 < rows && c0 < cols;  // rows, cols multiples of 32: a 4-lane block group is all-active or all-inactive
+  const float rcp = 1.0f / fp8_max_of<MI_FMT_E4M3>();
+  float f[8][8];
+  unsigned long long nanmask = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (active) {
+      const int64_t idx = ((r0 + i) * cols + c0) >> 3;
+      v4i pv = reinterpret_cast<const v4i*>(p)[idx];
+      const v4i gv = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(g) + idx);
+      v4i mv = reinterpret_cast<const v4i*>(m)[idx];
+      v4i vv = reinterpret_cast<const v4i*>(v)[idx];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float pl = __uint_as_float((u32)pv[j] << 16), ph = __uint_as_float((u32)pv[j] & 0xFFFF0000u);
+        const float gl = gs * __uint_as_float((u32)gv[j] << 16), gh = gs * __uint_as_float((u32)gv[j] & 0xFFFF0000u);
+        float ml = __uint_as_float((u32)mv[j] << 16), mh = __uint_as_float((u32)mv[j] & 0xFFFF0000u);
+        float vl = __uint_as_float((u32)vv[j] << 16), vh = __uint_as_float((u32)vv[j] & 0xFFFF0000u);
+        adam_one(pl, gl, ml, vl, a);
+        adam_one(ph, gh, mh, vh, a);
+        const u32 pw = pack_bf16x2(pl, ph);
+        pv[j] = (int)pw;
+        mv[j] = (int)pack_bf16x2(ml, mh);
+        vv[j] = (int)pack_bf16x2(vl, vh);
+        f[i][2 * j] = __uint_as_float(pw << 16);  // the ROUNDED weight: what the next forward's quantiser would read
+        f[i][2 * j + 1] = __uint_as_float(pw & 0xFFFF0000u);
+      }
+      reinterpret_cast<v4i*>(p)[idx] = pv;
+      reinterpret_cast<v4i*>(m)[idx] = mv;
+      reinterpret_cast<v4i*>(v)[idx] = vv;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[i][j] = 0.0f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (f[i][j] != f[i][j]) {  // as mxfp8_quant_kernel: a NaN does not enter the block amax and leaves as 0x7F
+        nanmask |= 1ull << (8 * i + j);
+        f[i][j] = 0.0f;
+      }
+  auto patch4 = [&](u32 w, int bit0) -> u32 {
+    if (__builtin_expect(nanmask != 0, 0)) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if ((nanmask >> (bit0 + k)) & 1) w = (w & ~(0xFFu << (8 * k))) | (0x7Fu << (8 * k));
+    }
+    return w;
+  };
+  typedef unsigned int v2u_ __attribute__((ext_vector_type(2)));
+  {  // row-wise blocks (32 columns = 4 lanes)
+    u32 sbytes[8], lo[8], hi[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float am = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) am = fmaxf(am, fabsf(f[i][j]));
+      am = fmaxf(am, __shfl_xor(am, 1));
+      am = fmaxf(am, __shfl_xor(am, 2));
+      const u32 e = e8m0_roundup(am * rcp);
+      const float inv = e8m0_inv(e);
+      sbytes[i] = e;
+      lo[i] = patch4(cvt4_fp8<MI_FMT_E4M3>(f[i][0] * inv, f[i][1] * inv, f[i][2] * inv, f[i][3] * inv), 8 * i);
+      hi[i] = patch4(cvt4_fp8<MI_FMT_E4M3>(f[i][4] * inv, f[i][5] * inv, f[i][6] * inv, f[i][7] * inv), 8 * i + 4);
+    }
+    if (active) {
+      uint8_t* dst = y_row + r0 * cols + c0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const v2u_ w = {lo[i], hi[i]};
+        __builtin_nontemporal_store(w, reinterpret_cast<v2u_*>(dst + (int64_t)i * cols));
+      }
+      if ((lane & 3) == 0) {
+        const v2u_ w = {sbytes[0] | (sbytes[1] << 8) | (sbytes[2] << 16) | (sbytes[3] << 24),
+                        sbytes[4] | (sbytes[5] << 8) | (sbytes[6] << 16) | (sbytes[7] << 24)};
+        *reinterpret_cast<v2u_*>(s_row + (c0 / 32) * ldr + r0) = w;
+      }
+    }
+  }
+  {  // column-wise blocks (32 rows = 4 lane rows), stored transposed
+    u32 sbytes[8];
+    float inv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float am = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) am = fmaxf(am, fabsf(f[i][j]));
+      am = fmaxf(am, __shfl_xor(am, 8));
+      am = fmaxf(am, __shfl_xor(am, 16));
+      const u32 e = e8m0_roundup(am * rcp);
+      sbytes[j] = e;
+      inv[j] = e8m0_inv(e);
+    }
+    u32 lo[8], hi[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      lo[i] = patch4(cvt4_fp8<MI_FMT_E4M3>(f[i][0] * inv[0], f[i][1] * inv[1], f[i][2] * inv[2], f[i][3] * inv[3]), 8 * i);
+      hi[i] = patch4(cvt4_fp8<MI_FMT_E4M3>(f[i][4] * inv[4], f[i][5] * inv[5], f[i][6] * inv[6], f[i][7] * inv[7]), 8 * i + 4);
+    }
+    if (active) {
+      u32 ta[4], tb[4], tc[4], td[4];
+      transpose4x4(lo[0], lo[1], lo[2], lo[3], ta[0], ta[1], ta[2], ta[3]);
+      transpose4x4(lo[4], lo[5], lo[6], lo[7], tb[0], tb[1], tb[2], tb[3]);
+      transpose4x4(hi[0], hi[1], hi[2], hi[3], tc[0], tc[1], tc[2], tc[3]);
+      transpose4x4(hi[4], hi[5], hi[6], hi[7], td[0], td[1], td[2], td[3]);
+      uint8_t* dst = y_colT + c0 * ldr + r0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const v2u_ w0 = {ta[j], tb[j]}, w1 = {tc[j], td[j]};
+        __builtin_nontemporal_store(w0, reinterpret_cast<v2u_*>(dst + (int64_t)j * ldr));
+        __builtin_nontemporal_store(w1, reinterpret_cast<v2u_*>(dst + (int64_t)(j + 4) * ldr));
+      }
+      if (((lane >> 3) & 3) == 0) {
+        const v2u_ w = {sbytes[0] | (sbytes[1] << 8) | (sbytes[2] << 16) | (sbytes[3] << 24),
+                        sbytes[4] | (sbytes[5] << 8) | (sbytes[6] << 16) | (sbytes[7] << 24)};
+        *reinterpret_cast<v2u_*>(s_colT + (r0 / 32) * cols + c0) = w;
+      }
+    }
+  }
+}
+
 // Embedding weight gradient added IN PLACE into an existing [V, H] bf16 gradient (the tied lm_head / embedding table already
 // holds the lm_head wgrad): grad[id, :] += alpha * sum over the tokens with that id of dY[token, :].  Replaces
 // aten::embedding_dense_backward (zero-fill of a dense [V, H] + scatter) followed by a dense add -- 2 x 788 MB written and
@@ -433,6 +626,17 @@ extern "C" int mi_adamw_cast_bf16_multi(const int64_t* table, int n_tensors, con
   hipLaunchKernelGGL(mi::adamw_cast_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, table, n_tensors,
                      (const mi::ChunkRef*)chunks, chunk_elems, grad_scale, make_adam_args(lr, beta1, beta2, eps, weight_decay, step));
   MI_CHECK_LAUNCH("mi_adamw_cast_bf16_multi launch");
+  return MI_OK;
+}
+
+extern "C" int mi_adamw_mxcast_bf16_multi(const int64_t* table, int n_tensors, const int32_t* chunks, int n_chunks, int chunk_elems,
+                                          const float* grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                          int64_t step, void* stream) {
+  MI_CHECK_ARG(table && chunks, "mi_adamw_mxcast_bf16_multi: null pointer");
+  MI_CHECK_ARG(n_tensors >= 1 && n_chunks >= 1 && chunk_elems >= 8 && chunk_elems % 8 == 0 && step >= 1, "mi_adamw_mxcast_bf16_multi: bad sizes");
+  hipLaunchKernelGGL(mi::adamw_mxcast_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, table, n_tensors,
+                     (const mi::ChunkRef*)chunks, chunk_elems, grad_scale, make_adam_args(lr, beta1, beta2, eps, weight_decay, step));
+  MI_CHECK_LAUNCH("mi_adamw_mxcast_bf16_multi launch");
   return MI_OK;
 }
 

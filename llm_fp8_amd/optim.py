@@ -53,15 +53,28 @@ class ClippedAdamW(torch.optim.Optimizer):
             return None
         return s
 
-    def _plan(self, group_items, dev):
+    @staticmethod
+    def _mx_sink_of(p):
+        """(sink, row offset, rows) when the MXFP8 copies of this weight are kept current by the optimiser (module.MXWeightSink)."""
+        if os.environ.get("LLM_FP8_AMD_NO_OPT_WCAST") == "1":
+            return None
+        s = getattr(p, "_mi_mx_sink", None)
+        if s is None or not p.is_contiguous() or p.dim() != 2:
+            return None
+        sink, r0, n = s
+        if n != p.shape[0] or sink.w8.shape[1] != p.shape[1] or p.shape[0] % 32 or p.shape[1] % 32 or r0 % 32:
+            return None
+        return s
+
+    def _plan(self, group_items, dev, mx=False):
         """Device tables of one parameter group for the multi-tensor kernels.  The chunk lists only depend on the tensor sizes
         (and on which tensors have an FP8 sink) and are built once; the address table is re-uploaded when an address changed
         (gradients are new tensors every step, though the caching allocator usually hands back the same blocks)."""
         # one plan per PARTITION (the parameters of a group that share a step count), not per group: two partitions of one
         # group must not share address table / partial sums
-        key = (id(group_items[0][0]), tuple(id(p) for _, p in group_items))
+        key = (id(group_items[0][0]), tuple(id(p) for _, p in group_items), mx)
         sizes = tuple(p.numel() for _, p in group_items)
-        sinks = tuple(self._sink_of(p) for _, p in group_items)
+        sinks = tuple((self._mx_sink_of(p) if mx else self._sink_of(p)) for _, p in group_items)
         sink_sig = tuple(None if s is None else (id(s[0]), s[1]) for s in sinks)
         plan = self._plans.get(key)
         if plan is None or plan["sizes"] != sizes or plan["sink_sig"] != sink_sig:
@@ -93,6 +106,16 @@ class ClippedAdamW(torch.optim.Optimizer):
             if s is None:
                 for r in range(5, 12):
                     rows[r].append(0)
+            elif mx:  # mi_adamw_mxcast_bf16_multi: 6 y_row  7 s_row  8 y_colT  9 s_colT  10 ldr  11 unused
+                sink, r0, _ = s
+                K, N = p.shape[1], sink.w8.shape[0]
+                rows[5].append(K)
+                rows[6].append(sink.w8.data_ptr() + r0 * K)
+                rows[7].append(sink.sc.data_ptr() + r0)
+                rows[8].append(sink.wt8.data_ptr() + r0)
+                rows[9].append(sink.sct.data_ptr() + (r0 // 32) * K)
+                rows[10].append(N)
+                rows[11].append(0)
             else:
                 sink, r0, _ = s
                 K, N = p.shape[1], sink.w8.shape[0]
@@ -105,6 +128,7 @@ class ClippedAdamW(torch.optim.Optimizer):
                 rows[10].append(sink.scale.data_ptr())
                 rows[11].append(sink.amax.data_ptr())
         plan["sinks"] = sinks
+        plan["mx"] = mx
         if plan["addr"] != rows:
             # two pinned staging buffers, each guarded by an event recorded behind its last upload: the host may run several
             # steps ahead of the device, and rewriting a buffer whose async H2D copy has not run yet would hand the kernels
@@ -143,8 +167,9 @@ class ClippedAdamW(torch.optim.Optimizer):
             if not p.grad.is_contiguous():
                 p.grad = p.grad.contiguous()
             assert p.is_contiguous()
-            by_group.setdefault((id(group), state["step"]), []).append((group, p))
-        plans = [(gi, self._plan(gi, dev)) for gi in by_group.values()]
+            # weights with an MXFP8 sink form partitions of their own (another kernel and another table layout)
+            by_group.setdefault((id(group), state["step"], self._mx_sink_of(p) is not None), []).append((group, p))
+        plans = [(gi, self._plan(gi, dev, mx=key[2])) for key, gi in by_group.items()]
         coef_ptr = None
         if self.max_grad_norm is not None:
             # squared norm: one launch per parameter group, one fp32 partial per 64 Ki-element chunk, fixed summation order
@@ -174,10 +199,11 @@ class ClippedAdamW(torch.optim.Optimizer):
                 self.state[p]["step"] += 1
             b1, b2 = group["betas"]
             if plan["chunks_cast"] is not None:  # some weights of this partition have FP8 sinks: update + cast in one pass
-                rc = lib.mi_adamw_cast_bf16_multi(plan["table"].data_ptr(), len(gi), plan["chunks_cast"].data_ptr(), plan["n_chunks_cast"],
+                fn = lib.mi_adamw_mxcast_bf16_multi if plan["mx"] else lib.mi_adamw_cast_bf16_multi
+                rc = fn(plan["table"].data_ptr(), len(gi), plan["chunks_cast"].data_ptr(), plan["n_chunks_cast"],
                                                   self.CHUNK, coef_ptr, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
                                                   int(self.state[gi[0][1]]["step"]), st)
-                _lib.check(rc, "mi_adamw_cast_bf16_multi")
+                _lib.check(rc, "mi_adamw_mxcast_bf16_multi" if plan["mx"] else "mi_adamw_cast_bf16_multi")
             else:
                 rc = lib.mi_adamw_bf16_multi(plan["table"].data_ptr(), len(gi), plan["chunks"].data_ptr(), plan["n_chunks"], self.CHUNK,
                                              coef_ptr, float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],

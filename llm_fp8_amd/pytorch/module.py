@@ -141,6 +141,50 @@ def weight_sinks_enabled() -> bool:
     return os.environ.get("LLM_FP8_AMD_NO_OPT_WCAST") != "1"
 
 
+class MXWeightSink:
+    """MXFP8 copies (row-wise w8 [N,K] + E8M0 [K/32,N]; column-wise, stored transposed, wt8 [K,N] + E8M0 [N/32,K]) of one GEMM's
+    weight operand that the OPTIMISER keeps current (optim.ClippedAdamW -> mi_adamw_mxcast_bf16_multi).  Block scaling has no
+    state, so the only condition for using them is that nobody wrote the weights since: `stamp` = versions of the parts."""
+    __slots__ = ("w8", "sc", "wt8", "sct", "parts", "stamp")
+
+    def __init__(self, weights, ns, N, K, dev):
+        self.w8 = torch.empty((N, K), dtype=torch.uint8, device=dev)
+        self.sc = torch.empty((K // 32, N), dtype=torch.uint8, device=dev)
+        self.wt8 = torch.empty((K, N), dtype=torch.uint8, device=dev)
+        self.sct = torch.empty((N // 32, K), dtype=torch.uint8, device=dev)
+        self.parts, r = [], 0
+        for w, n in zip(weights, ns):
+            self.parts.append((w, r, n))
+            w._mi_mx_sink = (self, r, n)
+            r += n
+        self.stamp = None
+
+    def fresh(self) -> bool:
+        return self.stamp is not None and self.stamp == tuple(w._version for w, _, _ in self.parts)
+
+    def mark(self) -> None:  # called by the optimiser after it rewrote every part in this step
+        self.stamp = tuple(w._version for w, _, _ in self.parts)
+
+
+def _mx_sink_copies(spec: _GemmSpec, g: int, weights, ns, N: int, K: int, dev):
+    """(w8, sc, wt8, sct) from the optimiser-maintained sink of GEMM `g` if they are current, else None (the caller quantises).
+    A training pass creates the sink the first time round; the optimiser fills it at its next step."""
+    if spec.wcache is None or spec.fmt_fwd != 0 or not weight_sinks_enabled():
+        return None
+    sink = spec.wcache.get(("mxsink", g))
+    stale = sink is None or len(sink.parts) != len(weights) or any(a is not b for (a, _, _), b in zip(sink.parts, weights))
+    if stale:
+        if not spec.training:
+            return None
+        ok = (N % 32 == 0 and K % 32 == 0 and all(n % 32 == 0 for n in ns) and
+              all(isinstance(w, torch.nn.Parameter) and w.dtype == torch.bfloat16 and w.is_contiguous() and w.dim() == 2 and w.shape[1] == K
+                  for w in weights))
+        if not ok:
+            return None
+        sink = spec.wcache[("mxsink", g)] = MXWeightSink(weights, ns, N, K, dev)
+    return (sink.w8, sink.sc, sink.wt8, sink.sct) if sink.fresh() else None
+
+
 def _cast_weights(spec: _GemmSpec, g: int, weights, ns, N: int, K: int, dev, need_t: bool):
     """FP8 copies (w8 [N,K], w8T [K,N]) of the concatenated weight parts of GEMM `g` under delayed scaling, plus the
     scale_inv they were quantised with.  Honours the micro-batch cache of the spec (see _GemmSpec)."""
@@ -316,7 +360,11 @@ class _FP8LinearFn(torch.autograd.Function):
             if hit is not None and (hit[2] is not None or not need_dgrad):
                 w8, ws, wt8, wts = hit
             else:
-                w8, ws, wt8, wts = _mx_quantize_weights(weights, ns, N, K, spec.fmt_fwd, need_dgrad or spec.first_mb is True)
+                kept = _mx_sink_copies(spec, spec.g, weights, ns, N, K, x2.device)
+                if kept is not None:
+                    w8, ws, wt8, wts = kept
+                else:
+                    w8, ws, wt8, wts = _mx_quantize_weights(weights, ns, N, K, spec.fmt_fwd, need_dgrad or spec.first_mb is True)
                 if spec.first_mb is True and spec.wcache is not None:
                     spec.wcache[ck] = (w8, ws, wt8, wts)
             y = ops.gemm_mxfp8(x8, xs, w8, ws, spec.fmt_fwd, spec.fmt_fwd, bias=bias_bf16)
@@ -463,8 +511,10 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
         hit = spec.wcache.get(ck) if (spec.first_mb is False and spec.wcache is not None) else None
         if hit is not None and (hit[2] is not None or not need_t):
             return hit
-        wb = (w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)).contiguous()
-        q = ops.mxfp8_quantize(wb, spec.fmt_fwd, rowwise=True, colwise=need_t or spec.first_mb is True)
+        q = _mx_sink_copies(spec, g, [w], [w.shape[0]], w.shape[0], w.shape[1], w.device)
+        if q is None:
+            wb = (w if w.dtype == torch.bfloat16 else w.to(torch.bfloat16)).contiguous()
+            q = ops.mxfp8_quantize(wb, spec.fmt_fwd, rowwise=True, colwise=need_t or spec.first_mb is True)
         if spec.first_mb is True and spec.wcache is not None:
             spec.wcache[ck] = q
         return q

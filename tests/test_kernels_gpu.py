@@ -913,3 +913,56 @@ def test_grouped_gemm_rejects_what_it_cannot_take(ops, dev):
     with pytest.raises(RuntimeError, match="does not fit tile shape|no tile shape"):
         ops.gemm_fp8_grouped([(a, a, one, one, o)], 0, 0)
     assert not ops.grouped_gemm_ok([(256, 256, 128)]) and ops.grouped_gemm_ok([(8192, 3072, 3072), (3072, 3072, 8192)])
+
+
+@pytest.mark.parametrize("shape,parts", [((256, 512), (256,)), ((1024, 384), (512, 256, 256)), ((160, 96), (96, 64))])
+def test_adamw_mxcast_emits_the_bytes_of_the_quantiser(ops, dev, shape, parts):
+    """mi_adamw_mxcast_bf16_multi: the updated bf16 weight is the one mi_adamw_bf16_multi produces, and the MXFP8 copies it emits
+    (row blocks + E8M0, column blocks transposed + E8M0, each part a row-block of one operand) are bitwise mi_mxfp8_quantize of
+    that updated weight."""
+    from llm_fp8_amd import _lib
+    lib = _lib.load()
+    N, K = shape
+    g = torch.Generator(device=dev).manual_seed(3)
+    ws = [torch.randn((n, K), generator=g, device=dev).to(torch.bfloat16) for n in parts]
+    gs = [(torch.randn((n, K), generator=g, device=dev) * 1e-2).to(torch.bfloat16) for n in parts]
+    ms = [(torch.randn((n, K), generator=g, device=dev) * 1e-3).to(torch.bfloat16) for n in parts]
+    vs = [(torch.rand((n, K), generator=g, device=dev) * 1e-4).to(torch.bfloat16) for n in parts]
+    ref = [t.clone() for t in ws], [t.clone() for t in ms], [t.clone() for t in vs]
+    st = torch.cuda.current_stream().cuda_stream
+    hp = dict(lr=1e-2, b1=0.9, b2=0.999, eps=1e-8, wd=0.01, step=3)
+
+    def table(rows):
+        return torch.tensor(rows, dtype=torch.int64).to(dev)
+
+    # reference: plain multi-tensor update, then the quantiser
+    T = len(parts)
+    chunks = torch.tensor([(t, c) for t in range(T) for c in range((ref[0][t].numel() + 65535) // 65536)], dtype=torch.int32).to(dev)
+    tab = table([[t.data_ptr() for t in ref[0]], [t.data_ptr() for t in gs], [t.data_ptr() for t in ref[1]], [t.data_ptr() for t in ref[2]],
+                 [t.numel() for t in ref[0]]])
+    _lib.check(lib.mi_adamw_bf16_multi(tab.data_ptr(), T, chunks.data_ptr(), chunks.shape[0], 65536, None, hp["lr"], hp["b1"], hp["b2"],
+                                        hp["eps"], hp["wd"], hp["step"], st), "ref")
+    q_ref = ops.mxfp8_quantize(torch.cat(ref[0], 0), 0, rowwise=True, colwise=True)
+    # under test
+    w8 = torch.zeros((N, K), dtype=torch.uint8, device=dev)
+    sc = torch.zeros((K // 32, N), dtype=torch.uint8, device=dev)
+    wt8 = torch.zeros((K, N), dtype=torch.uint8, device=dev)
+    sct = torch.zeros((N // 32, K), dtype=torch.uint8, device=dev)
+    rows = [[t.data_ptr() for t in ws], [t.data_ptr() for t in gs], [t.data_ptr() for t in ms], [t.data_ptr() for t in vs],
+            [t.numel() for t in ws], [K] * T, [], [], [], [], [N] * T, [0] * T]
+    r0, cks = 0, []
+    for t, n in enumerate(parts):
+        rows[6].append(w8.data_ptr() + r0 * K)
+        rows[7].append(sc.data_ptr() + r0)
+        rows[8].append(wt8.data_ptr() + r0)
+        rows[9].append(sct.data_ptr() + (r0 // 32) * K)
+        cks += [(t, c) for c in range(((n + 127) // 128) * ((K + 127) // 128))]
+        r0 += n
+    tab2, chunks2 = table(rows), torch.tensor(cks, dtype=torch.int32).to(dev)
+    _lib.check(lib.mi_adamw_mxcast_bf16_multi(tab2.data_ptr(), T, chunks2.data_ptr(), chunks2.shape[0], 65536, None, hp["lr"], hp["b1"],
+                                               hp["b2"], hp["eps"], hp["wd"], hp["step"], st), "mxcast")
+    torch.cuda.synchronize()
+    for a, b in zip(ws + ms + vs, ref[0] + ref[1] + ref[2]):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    for got, want, what in zip((w8, sc, wt8, sct), q_ref, ("row data", "row scales", "column data", "column scales")):
+        assert torch.equal(got, want), what

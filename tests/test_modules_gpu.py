@@ -642,6 +642,64 @@ def test_optimizer_weight_cast_handoff_is_bitwise_the_forward_cast(te, dev, scen
     assert n1 < n0, (n1, n0)   # weight casts really disappeared from the forwards that follow an optimiser step
 
 
+@pytest.mark.parametrize("accum", [1, 2])
+def test_optimizer_mxfp8_weight_handoff_is_bitwise_the_forward_quantiser(te, dev, accum, monkeypatch):
+    """module.MXWeightSink + mi_adamw_mxcast_bf16_multi: under MXFP8 the optimiser emits the row- and column-block copies (and
+    E8M0 scales) of every decoder weight for the next forward.  Against the ordinary route (every forward quantises its weights):
+    same losses, weights and Adam moments after 5 optimiser steps and an evaluation pass in between, bit for bit -- and the
+    forwards that follow an optimiser step stop quantising weights."""
+    from llm_fp8_amd import train
+    from llm_fp8_amd.pytorch.fp8 import FP8GlobalStateManager as G
+    from llm_fp8_amd.pytorch import ops as _ops
+
+    def run(disable):
+        G.reset()
+        if disable:
+            monkeypatch.setenv("LLM_FP8_AMD_NO_OPT_WCAST", "1")
+        else:
+            monkeypatch.delenv("LLM_FP8_AMD_NO_OPT_WCAST", raising=False)
+        calls = {"n": 0}
+        orig = _ops.mxfp8_quantize
+
+        def counting(x, *a, **k):
+            if isinstance(x, torch.nn.Parameter):
+                calls["n"] += 1
+            return orig(x, *a, **k)
+
+        monkeypatch.setattr(_ops, "mxfp8_quantize", counting)
+        cfg = train.TrainingConfig(model_name="llama-3.2-3b", batch_size=2, max_seq_length=128, mixed_precision="fp8",
+                                   fp8_scenario="mxfp8", use_te=True, sharding_mode="none", num_hidden_layers=2, vocab_size=2048,
+                                   learning_rate=1e-3, num_warmup_steps=0)
+        torch.manual_seed(23)
+        device = torch.device(dev)
+        model = train.prepare_model(train.create_model(cfg, device), cfg)
+        opt, sched = train.create_optimizer(model, cfg)
+        model.train()
+        gen = torch.Generator(device=device).manual_seed(9)
+        losses = []
+        for _ in range(4):
+            mbs = [train.synthetic_batch(cfg, 2048, device, gen) for _ in range(accum)]
+            losses.append(train.train_step(model, mbs if accum > 1 else mbs[0], opt, sched, cfg).item())
+        model.eval()
+        with torch.no_grad():
+            ev = model(**train.synthetic_batch(cfg, 2048, device, gen)).loss.item()
+        model.train()
+        losses.append(train.train_step(model, train.synthetic_batch(cfg, 2048, device, gen), opt, sched, cfg).item())
+        flat = torch.cat([p.detach().reshape(-1).view(torch.int16) for p in model.parameters()]).clone()
+        mom = torch.cat([opt.state[p]["exp_avg_sq"].reshape(-1).view(torch.int16) for p in model.parameters() if p in opt.state]).clone()
+        monkeypatch.setattr(_ops, "mxfp8_quantize", orig)
+        return losses, ev, flat, mom, calls["n"]
+
+    try:
+        l1, e1, w1, m1, n1 = run(False)
+        l0, e0, w0, m0, n0 = run(True)
+    finally:
+        G.reset()
+    assert l1 == l0 and e1 == e0, (l1, l0)
+    assert torch.equal(w1, w0) and torch.equal(m1, m0)
+    assert n1 < n0, (n1, n0)
+
+
 def test_grouped_backward_gemms_change_nothing(te, dev, monkeypatch):
     """module._dgrad_wgrad: a Linear's dgrad + wgrad as ONE grouped launch (forced on for every eligible site through the autotune
     cache) against two launches: identical losses, weights and amax histories after 3 optimiser steps, bit for bit."""
