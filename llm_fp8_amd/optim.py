@@ -167,9 +167,20 @@ class ClippedAdamW(torch.optim.Optimizer):
             if not p.grad.is_contiguous():
                 p.grad = p.grad.contiguous()
             assert p.is_contiguous()
-            # weights with an MXFP8 sink form partitions of their own (another kernel and another table layout)
-            by_group.setdefault((id(group), state["step"], self._mx_sink_of(p) is not None), []).append((group, p))
-        plans = [(gi, self._plan(gi, dev, mx=key[2])) for key, gi in by_group.items()]
+            by_group.setdefault((id(group), state["step"]), []).append((group, p))
+        # The squared norm is taken over the partitions above (ONE fixed summation order, whatever sinks exist); the update of a
+        # partition that holds weights with an MXFP8 sink is split in two launches (another kernel and another table layout).
+        plans = [(gi, self._plan(gi, dev)) for gi in by_group.values()]
+        updates = []
+        for gi, plan in plans:
+            gi_mx = [it for it in gi if self._mx_sink_of(it[1]) is not None]
+            if gi_mx:
+                gi_rest = [it for it in gi if self._mx_sink_of(it[1]) is None]
+                updates.append((gi_mx, self._plan(gi_mx, dev, mx=True)))
+                if gi_rest:
+                    updates.append((gi_rest, self._plan(gi_rest, dev)))
+            else:
+                updates.append((gi, plan))
         coef_ptr = None
         if self.max_grad_norm is not None:
             # squared norm: one launch per parameter group, one fp32 partial per 64 Ki-element chunk, fixed summation order
@@ -193,7 +204,7 @@ class ClippedAdamW(torch.optim.Optimizer):
             coef = (self.max_grad_norm / (total + 1e-6)).clamp(max=1.0).reshape(1)  # clip_grad_norm_'s coefficient
             coef_ptr = coef.data_ptr()
         touched, sinks_seen = set(), {}
-        for gi, plan in plans:
+        for gi, plan in updates:
             group = gi[0][0]
             for _, p in gi:
                 self.state[p]["step"] += 1
