@@ -1441,6 +1441,8 @@ static int launch_fmt(const void* A, const void* B, void* D, const float* sa_inv
   } else if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 30) || (algo >= 40 && algo <= 46)) {
     return launch_p8<FA, FB>(a, b, (uint16_t*)D, sa_inv, sb_inv, (const uint8_t*)SA, (const uint8_t*)SB, bp, M, N, K, lda, ldb, ldd,
                              algo, mx, st);
+  } else if (algo >= 6 && algo <= 8 && !mx) {  // four-wave kernel (mi_gemm_w4.hip): 6 = product, 7 = no stores, 8 = clock stamps
+    return launch_w4(A, B, D, sa_inv, sb_inv, M, N, K, lda, ldb, ldd, FA, FB, algo - 6, algo == 8 ? (void*)bias : nullptr, st);
   } else if (algo == 13 && !mx) {
     int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
     hipLaunchKernelGGL((gemm_256_8ph<FA, FB, OUT, 1>), dim3(tiles_m * tiles_n), dim3(512), 0, st, a, b, D, sa_inv, sb_inv,
@@ -1501,6 +1503,13 @@ static int pick_algo(int algo, int64_t M, int64_t N, int64_t K, int64_t lda, int
   if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 30) || (algo >= 40 && algo <= 46)) {
     if (!p8_ok) {
       set_error("%s: algo %d needs M,N %% 256 (or 192) == 0, K %% 256 == 0, bf16 output, operands < 2 GiB", who, algo);
+      return MI_ERR_SHAPE;
+    }
+    return algo;
+  }
+  if (algo >= 6 && algo <= 8) {
+    if (!(p8_ok && M % 256 == 0 && N % 256 == 0)) {
+      set_error("%s: algo %d needs M,N,K %% 256 == 0, bf16 output, operands < 2 GiB", who, algo);
       return MI_ERR_SHAPE;
     }
     return algo;

@@ -107,6 +107,10 @@ __device__ __forceinline__ void wait_vmcnt() {
   __builtin_amdgcn_s_barrier();   \
   __builtin_amdgcn_sched_barrier(0);
 
+// mi_gemm_w4.hip: the four-wave (128x128 wave tile) kernel.  variant 0 = product, 1 = no stores, 2 = clock stamps (dbg)
+int launch_w4(const void* A, const void* B, void* D, const float* sa_inv, const float* sb_inv, int64_t M, int64_t N, int64_t K,
+              int64_t lda, int64_t ldb, int64_t ldd, int fa, int fb, int variant, void* dbg, hipStream_t st);
+
 static inline int num_cus() {
   static int n = 0;  // benign race: every thread computes the same value
   if (n == 0) {

@@ -1,7 +1,9 @@
-"""GPU: parity at the BASELINE.json configurations that round 1 left untested -- every FP8 GEMM of Llama-3.1-8B (batch 12 x seq 512,
-M = 6144: config #4/#5) and of Llama-3.2-1B (batch 16 x seq 512, M = 8192: config #2) at FULL size through `algo=0` (the tile-shape
-picker, mi_gemm.hip pick_tile_cfg), checked against the float64 oracle on a 256 x 256 sample of the output computed over the full K;
-one Llama-3.1-8B-WIDTH decoder layer (hybrid recipe) against HF's bf16 layer.  Shapes: SURVEY.md Appendix B."""
+"""GPU: parity at the BASELINE.json configurations at FULL size -- every FP8 GEMM of Llama-3.2-3B (batch 16 x seq 512, M = 8192: the
+HEADLINE configuration and config #3, incl. the lm_head with N = 128 256), of Llama-3.1-8B (batch 12 x seq 512, M = 6144: config
+#4/#5) and of Llama-3.2-1B (M = 8192: config #2) through `algo=0` (the tile-shape picker, mi_gemm.hip pick_tile_cfg), checked against
+the float64 oracle on a 256 x 256 sample of the output computed over the full K; the same 3B shapes through the block-scaled GEMM
+(config #3) and through the grouped dgrad + wgrad launch the training step uses; one Llama-3.1-8B-WIDTH decoder layer (hybrid recipe)
+against HF's bf16 layer.  Shapes: SURVEY.md Appendix B; the headline config is /root/reference/README.md:29."""
 import numpy as np
 import pytest
 import torch
@@ -12,6 +14,7 @@ from tests.util import dequant_table
 pytestmark = pytest.mark.gpu
 
 MODELS = {  # name -> (M, {site: (N, K)})
+    "3b": (8192, {"qkv": (5120, 3072), "o": (3072, 3072), "fc1": (16384, 3072), "fc2": (3072, 8192), "lm_head": (128256, 3072)}),
     "8b": (6144, {"qkv": (6144, 4096), "o": (4096, 4096), "fc1": (28672, 4096), "fc2": (4096, 14336)}),
     "1b": (8192, {"qkv": (3072, 2048), "o": (2048, 2048), "fc1": (16384, 2048), "fc2": (2048, 8192)}),
 }
@@ -37,6 +40,27 @@ def _rand_bytes(shape, fmt, gen, dev):
     return t
 
 
+def _assert_sample_matches_float64(d, a8, b8, fa, fb, alpha, what, sa_e8m0=None, sb_e8m0=None):
+    """256 x 256 sample of the output (rows / columns drawn over the whole matrix plus the neighbourhoods of the tile edges)
+    against the float64 product of the decoded operands over the FULL K; `s*_e8m0`: block-major [K/32, rows] E8M0 scales (MXFP8)."""
+    dev = d.device
+    M, N = d.shape
+    rs = np.random.default_rng(M + N)
+    rows = np.unique(np.concatenate([rs.choice(M, 240, replace=False), [0, 1, 255, 256, M - 257, M - 256, M - 2, M - 1]]))
+    cols = np.unique(np.concatenate([rs.choice(N, 240, replace=False), [0, 1, 191, 192, 255, 256, N - 193, N - 192, N - 2, N - 1]]))
+    tr, tc = torch.from_numpy(rows).to(dev), torch.from_numpy(cols).to(dev)
+    a_s = O.fp8_decode(a8[tr].cpu().numpy(), fa).astype(np.float64)
+    b_s = O.fp8_decode(b8[tc].cpu().numpy(), fb).astype(np.float64)
+    if sa_e8m0 is not None:
+        a_s *= np.repeat(O.e8m0_to_f32(sa_e8m0[:, tr].t().contiguous().cpu().numpy()).astype(np.float64), 32, axis=1)
+        b_s *= np.repeat(O.e8m0_to_f32(sb_e8m0[:, tc].t().contiguous().cpu().numpy()).astype(np.float64), 32, axis=1)
+    ref = (a_s @ b_s.T) * np.float64(alpha)
+    got = d[tr][:, tc].float().cpu().numpy().astype(np.float64)
+    tol = O.gemm_tolerance(ref)          # |d| <= 2^-7 |ref| + 1e-3 rms(ref)   (SURVEY.md 8c)
+    bad = np.abs(got - ref) > tol
+    assert not bad.any(), f"{what}: {bad.sum()} of {bad.size} sampled outputs outside tolerance"
+
+
 @pytest.mark.parametrize("fa,fb", [(O.E4M3, O.E4M3), (O.E5M2, O.E4M3)])
 @pytest.mark.parametrize("name,M,N,K", CASES, ids=[c[0] for c in CASES])
 def test_full_size_gemm_through_the_picker_vs_float64_oracle_sample(ops, name, M, N, K, fa, fb):
@@ -47,18 +71,8 @@ def test_full_size_gemm_through_the_picker_vs_float64_oracle_sample(ops, name, M
     sb = torch.tensor([1 / 0.013], dtype=torch.float32, device=dev)
     d = ops.gemm_fp8(a8, b8, sa, sb, fa, fb, algo=0)
     assert d.shape == (M, N) and d.dtype == torch.bfloat16
-    # 256 x 256 sample: rows / columns drawn over the whole output, plus the four corners' neighbourhoods (tile edges)
-    rs = np.random.default_rng(M + N)
-    rows = np.unique(np.concatenate([rs.choice(M, 240, replace=False), [0, 1, 255, 256, M - 257, M - 256, M - 2, M - 1]]))
-    cols = np.unique(np.concatenate([rs.choice(N, 240, replace=False), [0, 1, 191, 192, 255, 256, N - 193, N - 192, N - 2, N - 1]]))
-    a_s = O.fp8_decode(a8[torch.from_numpy(rows).to(dev)].cpu().numpy(), fa).astype(np.float64)
-    b_s = O.fp8_decode(b8[torch.from_numpy(cols).to(dev)].cpu().numpy(), fb).astype(np.float64)
     alpha = np.float32(sa.item()) * np.float32(sb.item())
-    ref = (a_s @ b_s.T) * np.float64(alpha)
-    got = d[torch.from_numpy(rows).to(dev)][:, torch.from_numpy(cols).to(dev)].float().cpu().numpy().astype(np.float64)
-    tol = O.gemm_tolerance(ref)          # |d| <= 2^-7 |ref| + 1e-3 rms(ref)   
-    bad = np.abs(got - ref) > tol
-    assert not bad.any(), f"{name} {M}x{N}x{K}: {bad.sum()} of {bad.size} sampled outputs outside tolerance"
+    _assert_sample_matches_float64(d, a8, b8, fa, fb, alpha, f"{name} {M}x{N}x{K}")
     # size-independent property on the FULL output: linearity in alpha (bit-exact for a power-of-two factor)
     d2 = ops.gemm_fp8(a8, b8, sa * 0.5, sb, fa, fb, algo=0)
     assert torch.equal(d2.float(), d.float() * 0.5)
@@ -66,11 +80,59 @@ def test_full_size_gemm_through_the_picker_vs_float64_oracle_sample(ops, name, M
     ta, tb = dequant_table(fa, dev), dequant_table(fb, dev)
     step = 1024
     bt = tb[b8.long()].t().contiguous()
-    for r0 in range(0, M, step * 4):   # every 4th slab of 1024 rows: bounded time, all columns
+    for r0 in range(0, M, step * (4 if M <= 32768 else 16)):   # every 4th (16th) slab of 1024 rows: bounded time, all columns
         refd = (ta[a8[r0:r0 + step].long()] @ bt) * float(alpha)
         diff = (d[r0:r0 + step].float() - refd).abs()
         rms = refd.pow(2).mean().sqrt()
         assert bool((diff <= 2.0 ** -7 * refd.abs() + 2e-3 * rms).all()), f"{name}: rows {r0}.. differ from the device fp32 matmul"
+
+
+CASES_3B = [c for c in CASES if c[0].startswith("3b-")]
+
+
+@pytest.mark.parametrize("name,M,N,K", CASES_3B, ids=[c[0] for c in CASES_3B])
+def test_3b_full_size_block_scaled_gemm_vs_float64_oracle_sample(ops, name, M, N, K):
+    """BASELINE config #3 (Llama-3.2-3B, --fp8_scenario mxfp8; /root/reference/te_llama_mxfp8.py:28-29): every decoder GEMM of the
+    step through mi_gemm_mxfp8 (auto = the persistent block-scaled kernel and its tile-shape picker) at full size; the E8M0 scales
+    span 2^-7 .. 2^+3 per 32-element block.  Plus linearity: +1 on every A-side exponent doubles the output bit for bit."""
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(hash((M, N, K)) % (2 ** 31))
+    a8, b8 = _rand_bytes((M, K), O.E4M3, gen, dev), _rand_bytes((N, K), O.E4M3, gen, dev)
+    sa = torch.randint(120, 131, (K // 32, M), generator=gen, device=dev, dtype=torch.uint8)
+    sb = torch.randint(120, 131, (K // 32, N), generator=gen, device=dev, dtype=torch.uint8)
+    d = ops.gemm_mxfp8(a8, sa, b8, sb)
+    assert d.shape == (M, N) and d.dtype == torch.bfloat16
+    _assert_sample_matches_float64(d, a8, b8, O.E4M3, O.E4M3, 1.0, f"mx {name} {M}x{N}x{K}", sa, sb)
+    d2 = ops.gemm_mxfp8(a8, sa + 1, b8, sb)
+    assert torch.equal(d2.float(), d.float() * 2.0)
+
+
+GROUPED_3B = [(s, 8192, N, K) for s, (N, K) in MODELS["3b"][1].items()]
+
+
+@pytest.mark.parametrize("fa", [O.E5M2, O.E4M3])  # grad_output format: HYBRID (attention) / E4M3 (the reference's MLP recipe)
+@pytest.mark.parametrize("site,M,N,K", GROUPED_3B, ids=[c[0] for c in GROUPED_3B])
+def test_3b_full_size_grouped_backward_pair_vs_float64_oracle_sample(ops, site, M, N, K, fa):
+    """The launch the 3B training step uses for a Linear's backward (dgrad dX[M,K] = G8 . W8T^T and wgrad dW[N,K] = G8T . X8T^T in ONE
+    mi_gemm_fp8_grouped launch; /root/reference/te_llama.py:77,80 call sites), at full size for every site incl. lm_head: both outputs
+    against the float64 sample AND bit for bit against the two separate launches."""
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(sum(map(ord, site)) * 7 + fa)
+    fb = O.E4M3
+    g8, w8t = _rand_bytes((M, N), fa, gen, dev), _rand_bytes((K, N), fb, gen, dev)
+    g8t, x8t = _rand_bytes((N, M), fa, gen, dev), _rand_bytes((K, M), fb, gen, dev)
+    sg = torch.tensor([1 / 211.0], dtype=torch.float32, device=dev)
+    sw = torch.tensor([1 / 0.7], dtype=torch.float32, device=dev)
+    sx = torch.tensor([1 / 5.3], dtype=torch.float32, device=dev)
+    if not ops.grouped_gemm_ok([(M, K, N), (N, K, M)]):
+        pytest.skip("not eligible for the grouped launch")
+    dx = torch.full((M, K), float("nan"), dtype=torch.bfloat16, device=dev)
+    dw = torch.full((N, K), float("nan"), dtype=torch.bfloat16, device=dev)
+    ops.gemm_fp8_grouped([(g8, w8t, sg, sw, dx), (g8t, x8t, sg, sx, dw)], fa, fb)
+    _assert_sample_matches_float64(dx, g8, w8t, fa, fb, np.float32(sg.item()) * np.float32(sw.item()), f"grouped {site} dgrad")
+    _assert_sample_matches_float64(dw, g8t, x8t, fa, fb, np.float32(sg.item()) * np.float32(sx.item()), f"grouped {site} wgrad")
+    assert torch.equal(dx.view(torch.int16), ops.gemm_fp8(g8, w8t, sg, sw, fa, fb, algo=4).view(torch.int16))
+    assert torch.equal(dw.view(torch.int16), ops.gemm_fp8(g8t, x8t, sg, sx, fa, fb, algo=4).view(torch.int16))
 
 
 def test_8b_width_decoder_layer_hybrid_tracks_hf_bf16():

@@ -567,39 +567,61 @@ def test_rmsnorm_cast_and_backward_vs_oracle(ops, dev, shape):
 
 @pytest.mark.parametrize("shape", [(32, 512), (160, 1024), (1024, 3072)])
 def test_mxfp8_fused_front_ends_vs_oracle(ops, dev, shape):
-    """MXFP8 quantiser fused with RMSNorm / SwiGLU / dSwiGLU == quantising the oracle's fp32 value, up to the device-exp
-    and bf16-input rounding edge cases (>= 99 % identical bytes, identical scales on >= 99.9 % of the blocks)."""
+    """MXFP8 quantiser fused with RMSNorm / SwiGLU / dSwiGLU (config #3 runs on these: /root/reference/te_llama_mxfp8.py:28-29), held
+    to the same criterion as the delayed-scaling twins: the kernels evaluate the float32 expressions of the oracle's *_device_order
+    restatements, so
+      * RMSNorm (no transcendental; the device's own rstd as input): E8M0 scales AND bytes identical, both orientations;
+      * SwiGLU / dSwiGLU (device v_exp_f32 vs numpy exp, a few ulps): a block scale may differ only by one step and only where the
+        block amax / 448 lies within 2^-17 of a power of two; with the device's scale every mismatching byte must belong to a value
+        within 2^-17 (+ the dsilu cancellation slack) of an FP8 rounding boundary."""
     R, C = shape
     g = torch.Generator().manual_seed(R + 3 * C)
-    to_bits = lambda f32: O.f32_to_bf16_bits(np.ascontiguousarray(f32, dtype=np.float32))
+    rcp = np.float32(1.0 / 448.0)
 
-    def check(got, val_f32, name):
-        # reference: quantise the fp32 value (the oracle's quantiser takes bf16 bits, so re-derive per block here)
+    def check(got, v32, name, exact, abs_slack=None):
         y_row, s_row, y_colT, s_colT = got
-        v = val_f32.astype(np.float32)
-        for data, scales, mat in ((y_row, s_row, v), (y_colT, s_colT, np.ascontiguousarray(v.T))):
+        v32 = np.ascontiguousarray(v32, dtype=np.float32)
+        for data, scales, mat, slk in ((y_row, s_row, v32, abs_slack),
+                                       (y_colT, s_colT, np.ascontiguousarray(v32.T), None if abs_slack is None else np.ascontiguousarray(abs_slack.T))):
             r, c = mat.shape
             blk = np.abs(mat).reshape(r, c // 32, 32).max(-1).astype(np.float32)
-            e = O.float_to_e8m0_roundup((blk * np.float32(1.0 / 448.0)).astype(np.float32))
-            inv = np.ldexp(np.float32(1.0), 127 - e.astype(np.int64)).astype(np.float32)
-            want = O.fp8_encode_sat((mat.reshape(r, c // 32, 32) * inv[:, :, None]).astype(np.float32).reshape(r, c), O.E4M3)
-            se = u8(scales).T
-            same_scale = (se == e)
-            assert same_scale.mean() >= 0.999, f"{name}: scale mismatch {1 - same_scale.mean():.5f}"
-            ok_blocks = np.repeat(same_scale, 32, axis=1)
-            assert (u8(data)[ok_blocks] == want[ok_blocks]).mean() >= 0.99, name
+            want_e = O.float_to_e8m0_roundup((blk * rcp).astype(np.float32))
+            got_e = u8(scales).T
+            mism = got_e != want_e
+            if exact:
+                assert not mism.any(), f"{name}: {mism.sum()} block scales differ from the float32 restatement"
+            else:
+                v = (blk * rcp).astype(np.float64)[mism]
+                step = np.abs(got_e.astype(np.int32) - want_e.astype(np.int32))[mism]
+                p2 = np.exp2(np.round(np.log2(np.maximum(v, 1e-300))))
+                assert (step == 1).all() and (np.abs(v / p2 - 1.0) <= 2.0 ** -17).all(), f"{name}: a block scale differs away from a power-of-two boundary"
+                assert mism.sum() <= max(2, 1e-4 * mism.size), f"{name}: {mism.sum()} of {mism.size} block scales differ"
+            inv = np.ldexp(np.float32(1.0), 127 - got_e.astype(np.int64)).astype(np.float32)   # the DEVICE's scale
+            v_scaled = (mat.reshape(r, c // 32, 32) * inv[:, :, None]).astype(np.float32).reshape(r, c)
+            if exact:
+                np.testing.assert_array_equal(u8(data), O.fp8_encode_sat(v_scaled, O.E4M3), err_msg=name)
+            else:
+                slack = None if slk is None else (slk.reshape(r, c // 32, 32) * inv[:, :, None]).reshape(r, c)
+                _assert_matches_fp32_restatement(u8(data), v_scaled, O.E4M3, name, abs_slack=slack)
 
     x = (torch.randn(R, C, generator=g) * torch.exp(torch.randn(R, 1, generator=g))).to(torch.bfloat16)
     gamma = (torch.rand(C, generator=g) + 0.5).to(torch.bfloat16)
-    y_ref, rstd_ref = O.rmsnorm_f32(bf16_bits(x), bf16_bits(gamma), 1e-5)
     rstd = ops.rmsnorm_stats(x.to(dev), 1e-5)
-    check(ops.mxfp8_norm_quantize(x.to(dev), rstd, gamma.to(dev)), y_ref, "norm")
+    y32 = O.norm_apply_f32_device_order(bf16_bits(x), rstd.cpu().numpy(), bf16_bits(gamma))
+    check(ops.mxfp8_norm_quantize(x.to(dev), rstd, gamma.to(dev)), y32, "mx norm", exact=True)
+    y_ref, _ = O.rmsnorm_f32(bf16_bits(x), bf16_bits(gamma), 1e-5)   # and the float64-derived value: the restatement is the same function
+    np.testing.assert_allclose(y32, y_ref, rtol=2e-6, atol=0)
     h = (torch.randn(R, 2 * C, generator=g) * 2).to(torch.bfloat16)
-    check(ops.mxfp8_swiglu_quantize(h.to(dev)), O.swiglu_f32(bf16_bits(h)), "swiglu")
+    act32 = O.swiglu_f32_device_order(bf16_bits(h))
+    check(ops.mxfp8_swiglu_quantize(h.to(dev)), act32, "mx swiglu", exact=False)
+    np.testing.assert_allclose(act32, O.swiglu_f32(bf16_bits(h)), rtol=1e-5, atol=1e-30)
     d = (torch.randn(R, C, generator=g) / 8).to(torch.bfloat16)
     out = ops.mxfp8_dswiglu_quantize(h.to(dev), d.to(dev), want_colsum=True)
+    dh32 = O.dswiglu_f32_device_order(bf16_bits(h), bf16_bits(d))
+    hf, df = O.bf16_bits_to_f32(bf16_bits(h)), O.bf16_bits_to_f32(bf16_bits(d))
+    slack = np.concatenate([np.abs(df * hf[:, C:]) * 2.0 ** -21, np.zeros_like(df)], axis=1).astype(np.float32)
+    check(out[:4], dh32, "mx dswiglu", exact=False, abs_slack=slack)
     dh = O.dswiglu_f32(bf16_bits(h), bf16_bits(d))
-    check(out[:4], dh, "dswiglu")
     np.testing.assert_allclose(out[4].sum(0).cpu().numpy(), dh.astype(np.float64).sum(0), rtol=1e-4, atol=1e-4 * np.abs(dh).max() * np.sqrt(R))
 
 
