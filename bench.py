@@ -107,9 +107,9 @@ def linear_micro_baseline(model_name: str, M: int = 128, iters: int = 3):
 
 
 def gemm_clock_probe(sites, top: int = 4):
-    """In-kernel clock of the FP8 GEMM (MI355X_MICROARCH.md "DVFS give-back" item 6): the stamped diagnostic build (algo 21)
-    reports d(s_memtime) / d(s_memrealtime) x 100 MHz around each workgroup's whole tile walk; run after >= 1 s of back-to-back
-    launches of the production kernel on random FP8 bytes, for the `top` sites by time, time-weighted."""
+    """In-kernel clock of the FP8 GEMM (MI355X_MICROARCH.md "DVFS give-back" item 6): mi_gemm_fp8_clock (the production kernel with
+    two clock reads around each workgroup's whole tile walk) reports d(s_memtime) / d(s_memrealtime) x 100 MHz; run after >= 1 s of
+    back-to-back launches of the production kernel on random FP8 bytes, for the `top` sites by time, time-weighted."""
     from llm_fp8_amd import _lib
     lib = _lib.load()
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -129,16 +129,19 @@ def gemm_clock_probe(sites, top: int = 4):
         out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
         dbg = torch.zeros((256, 4), dtype=torch.int64, device=dev)
 
-        def run(algo, ptr):
-            rc = lib.mi_gemm_fp8(a.data_ptr(), b.data_ptr(), out.data_ptr(), one.data_ptr(), one.data_ptr(), ptr, m, n, k, k, k, n, 0, 0, 0, algo, st)
+        def run(ptr):
+            if ptr is None:
+                rc = lib.mi_gemm_fp8(a.data_ptr(), b.data_ptr(), out.data_ptr(), one.data_ptr(), one.data_ptr(), None, m, n, k, k, k, n, 0, 0, 0, 0, st)
+            else:
+                rc = lib.mi_gemm_fp8_clock(a.data_ptr(), b.data_ptr(), out.data_ptr(), one.data_ptr(), one.data_ptr(), m, n, k, k, k, n, 0, ptr, st)
             assert rc == 0, lib.mi_last_error()
 
         t0 = time.time()
         while time.time() - t0 < 1.0:
             for _ in range(40):
-                run(4, None)
+                run(None)
             torch.cuda.synchronize()
-        run(21, dbg.data_ptr())
+        run(dbg.data_ptr())
         torch.cuda.synchronize()
         d = dbg.cpu().double()
         d = d[d[:, 1] > 0]
@@ -294,7 +297,7 @@ def main():
                     if clk:
                         out["roofline"]["clock_ghz"] = clk
                         out["roofline"]["frac_at_clock"] = achieved / (FP8_DENSE_PEAK_TFLOPS * clk / 2.4)
-                        out["roofline"]["clock_note"] = ("in-kernel clock of the GEMM on random FP8 bytes: stamped build (algo 21), d(s_memtime)/d(s_memrealtime), "
+                        out["roofline"]["clock_note"] = ("in-kernel clock of the GEMM on random FP8 bytes: mi_gemm_fp8_clock, d(s_memtime)/d(s_memrealtime), "
                                                          "median over workgroups after 1 s of back-to-back launches, time-weighted over the top sites: "
                                                          + ", ".join(f"{t} {c:.2f} GHz" for t, c in per_site.items())
                                                          + "; frac_at_clock = achieved / (5000 TFLOP/s x clock / 2.4 GHz)")

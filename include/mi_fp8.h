@@ -56,8 +56,10 @@ extern "C" {
  *   2  round 2: mi_gemm_fp8 algo values 20-30, 46 (diagnostic builds), mi_adamw_cast_bf16_multi, mi_transpose_u8,
  *      mi_gemm_fp8_grouped
  *   3  round 2: mi_adamw_mxcast_bf16_multi
+ *   4  round 3: diagnostic algo values and mi_attn_fwd_diag moved out (lab build, -DMI_DIAG); mi_gemm_fp8 algos 6 and 9
+ *      (four-wave kernel); mi_gemm_fp8_clock
  */
-#define MI_ABI_VERSION 3
+#define MI_ABI_VERSION 4
 int mi_abi_version(void);
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* mi_last_error(void);
@@ -109,23 +111,33 @@ int mi_scale_update(float* amax_history, float* scale, float* scale_inv, const f
  *   D[m*ldd + n] = bf16( (sum_k A[m*lda+k] * B[n*ldb+k]) * (*sa_inv * *sb_inv) + bias[n] )
  * A: fp8 [M,K] fmt_a, B: fp8 [N,K] fmt_b, D: bf16 [M,N] (out_dtype 0) or fp32 (out_dtype 1).
  * bias: bf16 [N] or NULL.  M, N multiples of 16 (8 for the generic path), K multiple of 16.
- * algo: 0 = auto, 1 = generic 64x64 tile, 2 = 256x256 two-phase, 3 = 256x256 eight-phase ping-pong,
- *       4 = persistent eight-phase (one workgroup per CU, epilogue overlapped with the next tile).
- * 2/3 need M,N % 256 == 0 and K % 128 == 0; 4 additionally K % 256 == 0, bf16 output and operands
+ * algo: 0 = auto, 1 = generic 64x64 tile, 2 = 256x256 two-phase, 3 = 256x256 eight-phase ping-pong (eight waves),
+ *       4 = persistent eight-phase (one workgroup per CU, epilogue overlapped with the next tile),
+ *       5 = the kernel of 4 launched with one workgroup per tile (hardware-balanced: for use while collectives hold part of
+ *           the chip), 6 = four-wave kernel (128x128 wave tiles, one wave per SIMD; mi_gemm_w4.hip), one tile per workgroup,
+ *       9 = persistent four-wave kernel, 40-43 force one tile shape of 4, 44 = stream-K form of 4 (see mi_gemm_set_workspace),
+ *       45 = 4, 47 = auto that takes the persistent four-wave kernel where it is the faster one (no bias, 256-multiples,
+ *       K >= 512, and 256 x 256 is the eight-wave kernel's own tile choice), else as 0.
+ * 2/3/6 need M,N % 256 == 0 and K % 128 == 0 (6, 9: K % 256 == 0); 4 additionally K % 256 == 0, bf16 output and operands
  * below 2 GiB (M, N may also be multiples of 192: workgroup tiles of 256/192 rows x 256/192 columns are picked per shape).
- * auto picks 4, else 3, else 1.  5 = the kernel of 4 launched with one workgroup per tile (hardware-balanced: for use while
- * collectives hold part of the chip).  40-43 force one tile shape of 4, 44 = stream-K form of 4 (see mi_gemm_set_workspace),
- * 45 = 4.  Diagnostic / timing-only builds (E4M3 x E4M3 only; several give WRONG results or reinterpret `bias_bf16` as a
- * u64 debug buffer -- never use them in a product path): 13, 14 (eight-phase kernel: no stores / clock stamps), 15 no
- * epilogue stores, 16 start stagger (env MI_GEMM_STAGGER), 17 plain write-back stores, 18 / 19 MX scale-path ablations,
- * 20 every tile streams tile (0,0)'s panels (L2-perfect), 21 in-kernel clock stamps (`bias_bf16` = u64[4 * grid]),
- * 22 per-phase stamps of workgroup 0 (`bias_bf16` = u64[2048]), 24 half-line stores, 25 nt stores, 26 sc1+nt stores,
- * 27 epilogue woven into the MFMA segments, 28 no epilogue at all, 29 conversion woven / stores one load segment later (K >= 512), 30 odd tiles walk K downwards, 46 block epilogue after each tile (the round-1 form).  16 / 21 / 22 honour
- * env MI_GEMM_GRID (fewer workgroups).
+ * auto picks a persistent kernel when the shape allows, else 3, else 1.  Every algo listed here gives the SAME bits for the
+ * same inputs (one fp32 summation order per output element), tests/test_kernels_gpu.py.
+ * Not part of this library: the timing / ablation / stamp builds (algos 7, 8, 10-30, 46) live in the lab build
+ * (tools/bin/libmi_fp8_lab.so, `make -C llm_fp8_amd/csrc lab`, compiled with -DMI_DIAG; see tools/README.md); the product
+ * library returns MI_ERR_ARG for them.
  */
 int mi_gemm_fp8(const void* A, const void* B, void* D, const float* sa_inv, const float* sb_inv,
                 const void* bias_bf16, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
                 int64_t ldd, int fmt_a, int fmt_b, int out_dtype, int algo, void* stream);
+
+/*
+ * Measurement aid (bench.py `roofline.clock_ghz`): the persistent production kernel (algo 0 / 4 / 9 as mi_gemm_fp8 would run
+ * it, E4M3 x E4M3, no bias) with two clock reads around each workgroup's whole tile walk.  stamps: u64 [4 * workgroups] =
+ * {shader cycles (s_memtime), 100 MHz ticks (s_memrealtime), K-tile steps walked, XCC id} per workgroup; the output D is
+ * written as usual.  In-kernel clock = cycles / ticks x 100 MHz.
+ */
+int mi_gemm_fp8_clock(const void* A, const void* B, void* D, const float* sa_inv, const float* sb_inv, int64_t M, int64_t N,
+                      int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int algo, unsigned long long* stamps, void* stream);
 
 /*
  * Grouped form of mi_gemm_fp8: up to 4 independent problems D_p = (A_p . B_p^T) * (*sa_inv_p * *sb_inv_p), bf16 outputs, no
@@ -355,11 +367,13 @@ int mi_adamw_bf16(void* p_bf16, const void* g_bf16, void* exp_avg_bf16, void* ex
  */
 int mi_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int S, int H, int G, int D,
                 int64_t q_ts, int64_t k_ts, int64_t v_ts, int64_t o_ts, float scale, int causal, void* stream);
-/* Timing-only diagnostic build of the forward kernel (causal, D = 128): per wave, shader cycles spent in {S^T MFMAs + K fragment
+#ifdef MI_DIAG
+/* LAB BUILD ONLY (-DMI_DIAG).  Timing-only diagnostic build of the forward kernel (causal, D = 128): per wave, shader cycles spent in {S^T MFMAs + K fragment
  * reads, softmax arithmetic, P.V MFMAs + V fragment reads, stage stores incl. the wait for the next tile's loads, barrier};
  * dbg [B, H, S/128, 4 waves, 8] u64 (slot 5 = tiles walked).  Shares only: the stamps forbid overlaps the real kernel has. */
 int mi_attn_fwd_diag(const void* q, const void* k, const void* v, void* o, float* lse, unsigned long long* dbg, int B, int S,
                      int H, int G, int D, int64_t q_ts, int64_t k_ts, int64_t v_ts, int64_t o_ts, float scale, void* stream);
+#endif
 /*
  * Backward of mi_attn_fwd: P is recomputed from q, k and `lse`; two launches (dQ pass, which also writes
  * delta[B, H, S] = rowsum(dO * O), then the dK/dV pass), no sums across workgroups: results are bitwise reproducible.

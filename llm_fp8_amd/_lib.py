@@ -7,10 +7,12 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LLM_FP8_AMD_LIB") or os.path.join(_HERE, "libmi_fp8.so")  # the override is for A/B timing of another build of the same ABI
+# the lab build (same sources, -DMI_DIAG): timing / ablation / stamp builds for tools/ -- never loaded by the package itself
+LAB_LIB_PATH = os.path.join(os.path.dirname(_HERE), "tools", "bin", "libmi_fp8_lab.so")
 
 MI_FMT_E4M3 = 0
 MI_FMT_E5M2 = 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c_i64 = ctypes.c_int64
 _c_int = ctypes.c_int
@@ -66,15 +68,31 @@ SIGNATURES = {
     "mi_gemm_set_workspace": [_p, _c_i64],
     "mi_attn_fwd": [_p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_i64, ctypes.c_float,
                     _c_int, _p],
-    "mi_attn_fwd_diag": [_p, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_i64, ctypes.c_float, _p],
     "mi_attn_bwd": [_p] * 10 + [_c_int] * 5 + [_c_i64] * 8 + [ctypes.c_float, _c_int, _p],
     "mi_mxfp8_norm_quantize": [_p, _p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],
     "mi_mxfp8_swiglu_quantize": [_p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],
     "mi_mxfp8_dswiglu_quantize": [_p, _p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],
     "mi_gemm_mxfp8": [_p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_int, _p],
+    "mi_gemm_fp8_clock": [_p, _p, _p, _p, _p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _p, _p],
+}
+# entry points only the lab build exports (#ifdef MI_DIAG in include/mi_fp8.h)
+LAB_SIGNATURES = {
+    "mi_attn_fwd_diag": [_p, _p, _p, _p, _p, _p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_i64, ctypes.c_float, _p],
 }
 
 _lib = None
+
+
+def _bind(path: str, signatures) -> ctypes.CDLL:
+    lib = ctypes.CDLL(path)
+    for name, argtypes in signatures.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_char_p if name == "mi_last_error" else (_c_i64 if name == "mi_gemm_workspace_bytes" else _c_int)
+    v = lib.mi_abi_version()
+    if v != ABI_VERSION:
+        raise ImportError(f"{os.path.basename(path)} ABI version {v} != expected {ABI_VERSION}; rebuild it")
+    return lib
 
 
 def load() -> ctypes.CDLL:
@@ -87,16 +105,23 @@ def load() -> ctypes.CDLL:
             f"{LIB_PATH} not found: the HIP extension is not built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C llm_fp8_amd/csrc`. "
             "llm_fp8_amd has no CPU/PyTorch fallback for the FP8 path.")
-    lib = ctypes.CDLL(LIB_PATH)
-    for name, argtypes in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if the symbol is missing
-        fn.argtypes = argtypes
-        fn.restype = ctypes.c_char_p if name == "mi_last_error" else (_c_i64 if name == "mi_gemm_workspace_bytes" else _c_int)
-    v = lib.mi_abi_version()
-    if v != ABI_VERSION:
-        raise ImportError(f"libmi_fp8.so ABI version {v} != expected {ABI_VERSION}; rebuild it")
-    _lib = lib
-    return lib
+    _lib = _bind(LIB_PATH, SIGNATURES)
+    return _lib
+
+
+def use_lab_library() -> ctypes.CDLL:
+    """tools/ only: make every later call of this process go to the lab build (the product entry points + the diagnostic algo
+    values of mi_gemm_fp8 + mi_attn_fwd_diag).  Must run before anything loaded the product library."""
+    global _lib
+    if _lib is not None and getattr(_lib, "_mi_is_lab", False):
+        return _lib
+    if _lib is not None:
+        raise RuntimeError("use_lab_library(): the product library is already loaded in this process")
+    if not os.path.exists(LAB_LIB_PATH):
+        raise ImportError(f"{LAB_LIB_PATH} not found: run `make -C llm_fp8_amd/csrc lab`")
+    _lib = _bind(LAB_LIB_PATH, {**SIGNATURES, **LAB_SIGNATURES})
+    _lib._mi_is_lab = True
+    return _lib
 
 
 def check(rc: int, what: str = "") -> None:

@@ -47,17 +47,45 @@ def load_shard(file: str) -> Dict[str, torch.Tensor]:
     return load_file(file, device="cpu")
 
 
-def load_into(model: torch.nn.Module, path: str, config) -> List[str]:
+def load_into(model: torch.nn.Module, path: str, config, strict: bool = False) -> List[str]:
     """Copy a local HF-layout (or TE-layout) safetensors checkpoint into `model` shard by shard.
-    Returns the shard files read."""
+    Returns the shard files read.  Like the reference (`strict=False` per shard, te_llama.py:171) a shard may hold any subset of
+    the keys -- but what NO shard covered is reported: a warning lists the parameters that kept their initial values (a truncated
+    or mismatched shard set would otherwise load "successfully") and the checkpoint keys nothing consumed; `strict=True` raises."""
+    import warnings
     from .llama import replace_params
     shards = resolve_shards(path)
+    own = model.state_dict()
+    covered, fused, unexpected = set(), set(), set()
+    hf_fused = ("input_layernorm.weight", "self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
+                "self_attn.o_proj.weight", "post_attention_layernorm.weight", "mlp.down_proj.weight", "mlp.gate_proj.weight",
+                "mlp.up_proj.weight")
     for shard in shards:
         state = load_shard(shard)
-        replace_params(state, model.state_dict(), config)   # parameters that live under fused TE names
-        model.load_state_dict(state, strict=False)           # everything else (embeddings, final norm, lm_head, TE-named keys)
+        replace_params(state, own, config, written=fused)    # parameters that live under fused TE names
+        res = model.load_state_dict(state, strict=False)     # everything else (embeddings, final norm, lm_head, TE-named keys)
+        covered.update(k for k in state if k in own)
+        unexpected.update(k for k in res.unexpected_keys if not k.endswith(hf_fused))
         del state
         gc.collect()                                         # te_llama.py:174-176
+    for k in list(fused):
+        if "#" in k:  # fc1 = gate | up: covered when both halves arrived (or the TE-named tensor itself)
+            base = k.split("#")[0]
+            if base + "#gate" in fused and base + "#up" in fused:
+                covered.add(base)
+        else:
+            covered.add(k)
+    tied = bool(getattr(config, "tie_word_embeddings", False))
+    missing = sorted(k for k in own if k not in covered and not k.endswith("_extra_state")
+                     and not (tied and k == "lm_head.weight" and "model.embed_tokens.weight" in covered)
+                     and not k.endswith(("fc1_bias", "fc2_bias")))  # TE-only MLP biases: HF Llama has none (zero-initialised)
+    if missing or unexpected:
+        msg = (f"checkpoint {path}: {len(missing)} parameter(s) were in no shard and keep their initial values "
+               f"({missing[:8]}{' ...' if len(missing) > 8 else ''}); {len(unexpected)} checkpoint key(s) matched nothing "
+               f"({sorted(unexpected)[:8]}{' ...' if len(unexpected) > 8 else ''})")
+        if strict:
+            raise RuntimeError(msg)
+        warnings.warn(msg)
     extra = os.path.join(path, EXTRA_SINGLE)
     if os.path.isfile(extra):
         model.load_state_dict(load_shard(extra), strict=False)
@@ -109,7 +137,10 @@ def save_pretrained(model: torch.nn.Module, out_dir: str, config=None, layout: s
     else:
         raise ValueError(f"layout must be 'hf' or 'te', got {layout!r}")
     state = _dedupe_tied(state, config)
-    state = {k: v.detach().to("cpu").contiguous() for k, v in state.items() if isinstance(v, torch.Tensor)}
+    bad = [k for k, v in state.items() if not isinstance(v, torch.Tensor)]
+    if bad:  # safetensors holds tensors only; dropping an entry silently would save a checkpoint that restores differently
+        raise TypeError(f"save_pretrained: non-tensor state-dict entries cannot be written to safetensors: {bad[:8]}")
+    state = {k: v.detach().to("cpu").contiguous() for k, v in state.items()}
     shards = _shard(state, max_shard_bytes)
     written = []
     if len(shards) == 1:

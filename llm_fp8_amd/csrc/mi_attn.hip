@@ -610,6 +610,7 @@ extern "C" int mi_attn_fwd(const void* q, const void* k, const void* v, void* o,
   return MI_OK;
 }
 
+#ifdef MI_DIAG
 // timing-only diagnostic build of the forward kernel: per wave, cycles spent in {S^T MFMAs, softmax, P.V MFMAs, stage stores
 // (incl. the wait for the next tile's global loads), barrier}; dbg [B, H, S/128, 4 waves, 8] u64
 extern "C" int mi_attn_fwd_diag(const void* q, const void* k, const void* v, void* o, float* lse, unsigned long long* dbg, int B,
@@ -624,6 +625,7 @@ extern "C" int mi_attn_fwd_diag(const void* q, const void* k, const void* v, voi
   MI_CHECK_LAUNCH("mi_attn_fwd_diag launch");
   return MI_OK;
 }
+#endif  // MI_DIAG
 
 extern "C" int mi_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                            float* delta, void* dq, void* dk, void* dv, int B, int S, int H, int G, int D, int64_t q_ts,

@@ -1302,8 +1302,12 @@ static void launch_p8_cfg(const uint8_t* a, const uint8_t* b, uint16_t* D, const
   // one_tile_per_wg (algo 5): same kernel, one workgroup per tile, so the hardware dispatcher balances the tiles over whatever
   // CUs are free -- the form to use while other kernels (RCCL collectives) hold part of the chip
   int grid = (one_tile_per_wg || tiles_m * tiles_n < num_cus()) ? tiles_m * tiles_n : num_cus();
+#ifdef MI_DIAG
   if ((ABL == 3 || ABL == 8 || ABL == 9) && getenv("MI_GEMM_GRID")) grid = std::max(1, std::min(grid, atoi(getenv("MI_GEMM_GRID"))));  // experiment knob
   const int stagger = ((ABL == 3) && getenv("MI_GEMM_STAGGER")) ? atoi(getenv("MI_GEMM_STAGGER")) : 0;  // experiment knob (algo 16)
+#else
+  const int stagger = 0;
+#endif
   hipLaunchKernelGGL((gemm_256_p8<FA, FB, ABL, MX, BIAS, MA1, NB1, false, DEPI>), dim3(grid), dim3(512), 0, st, a, b, D, sa_inv, sb_inv, (int)K,
                      (int)lda, (int)ldb, (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb), (int)(M * ldd * 2), SA, SB,
                      (int)M, (int)N, bias, (float*)nullptr, (unsigned int*)nullptr, 0u, stagger);
@@ -1326,7 +1330,7 @@ static void launch_p8_sk(const uint8_t* a, const uint8_t* b, uint16_t* D, const 
 template <int FA, int FB>
 static int launch_p8(const uint8_t* a, const uint8_t* b, uint16_t* D, const float* sa_inv, const float* sb_inv,
                      const uint8_t* SA, const uint8_t* SB, const uint16_t* bias, int64_t M, int64_t N, int64_t K, int64_t lda,
-                     int64_t ldb, int64_t ldd, int algo, bool mx, hipStream_t st) {
+                     int64_t ldb, int64_t ldd, int algo, bool mx, hipStream_t st, void* clock_stamps = nullptr) {
   // algo 44: stream-K on 256x256 tiles (needs a registered workspace).  It is NOT part of the automatic choice: measured
   // (interleaved A/B) it loses 3-15 % to the best whole-tile shape at K <= 8192 and wins 3.5 % only at K = 16384 -- the chip
   // is power-limited, so a half-empty last round costs less than its CU count suggests (the busy CUs clock higher) while the
@@ -1365,6 +1369,7 @@ static int launch_p8(const uint8_t* a, const uint8_t* b, uint16_t* D, const floa
     case 2: MI_P8(MXv, BIASv, ABLv, 2, 2); break;                   \
     default: MI_P8(MXv, BIASv, ABLv, 2, 1); break;                  \
   }
+#ifdef MI_DIAG
   if (algo == 46 || (algo >= 15 && algo <= 30)) {  // timing-only / diagnostic builds: E4M3 x E4M3 only (compile time)
     if constexpr (FA == 0 && FB == 0) {
       if (algo == 46) {  // A/B baseline: block epilogue after each tile (the round-1 form)
@@ -1413,6 +1418,21 @@ static int launch_p8(const uint8_t* a, const uint8_t* b, uint16_t* D, const floa
       set_error("mi_gemm: diagnostic algo %d is built for E4M3 x E4M3 only", algo);
       return MI_ERR_ARG;
     }
+  } else
+#else
+  if (algo == 46 || (algo >= 15 && algo <= 30)) {
+    set_error("mi_gemm: algo %d is a timing / diagnostic build; it lives in the lab library (make -C llm_fp8_amd/csrc lab)", algo);
+    return MI_ERR_ARG;
+  } else
+#endif
+  if (clock_stamps != nullptr) {  // mi_gemm_fp8_clock: the production kernel's stamped build (E4M3 x E4M3 only)
+    if constexpr (FA == 0 && FB == 0) {
+      bias = (const uint16_t*)clock_stamps;
+      MI_P8_CFG(false, false, 8)
+    } else {
+      set_error("mi_gemm_fp8_clock: built for E4M3 x E4M3 only");
+      return MI_ERR_ARG;
+    }
   } else if (mx) {
     if (bias) { MI_P8_CFG(true, true, 0) } else { MI_P8_CFG(true, false, 0) }
   } else {
@@ -1427,7 +1447,7 @@ static int launch_p8(const uint8_t* a, const uint8_t* b, uint16_t* D, const floa
 template <int FA, int FB, int OUT>
 static int launch_fmt(const void* A, const void* B, void* D, const float* sa_inv, const float* sb_inv,
                       const void* SA, const void* SB, const void* bias, int64_t M, int64_t N, int64_t K,
-                      int64_t lda, int64_t ldb, int64_t ldd, int algo, bool mx, hipStream_t st) {
+                      int64_t lda, int64_t ldb, int64_t ldd, int algo, bool mx, hipStream_t st, void* clock_stamps = nullptr) {
   const uint8_t *a = (const uint8_t*)A, *b = (const uint8_t*)B;
   const uint16_t* bp = (const uint16_t*)bias;
   if (algo == 2 && !mx) {
@@ -1440,9 +1460,22 @@ static int launch_fmt(const void* A, const void* B, void* D, const float* sa_inv
                        bp, (int)M, (int)N, (int)K, lda, ldb, ldd, tiles_m, tiles_n);
   } else if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 30) || (algo >= 40 && algo <= 46)) {
     return launch_p8<FA, FB>(a, b, (uint16_t*)D, sa_inv, sb_inv, (const uint8_t*)SA, (const uint8_t*)SB, bp, M, N, K, lda, ldb, ldd,
-                             algo, mx, st);
-  } else if (algo >= 6 && algo <= 8 && !mx) {  // four-wave kernel (mi_gemm_w4.hip): 6 = product, 7 = no stores, 8 = clock stamps
-    return launch_w4(A, B, D, sa_inv, sb_inv, M, N, K, lda, ldb, ldd, FA, FB, algo - 6, algo == 8 ? (void*)bias : nullptr, st);
+                             algo, mx, st, clock_stamps);
+  } else if (algo >= 6 && algo <= 12 && !mx) {
+    // four-wave kernel (mi_gemm_w4.hip): one tile per workgroup 6 = product, 7 = no stores, 8 = clock stamps; persistent
+    // 9 = product, 10 = no stores, 11 = clock stamps, 12 = no epilogue (7, 8, 10-12: lab library only)
+    const int variant = algo <= 8 ? algo - 6 : algo + 1;
+    if (bp != nullptr && algo != 8 && algo != 11) {
+      set_error("mi_gemm: the four-wave kernels (algo %d) take no bias", algo);
+      return MI_ERR_ARG;
+    }
+    if (clock_stamps != nullptr) return launch_w4(A, B, D, sa_inv, sb_inv, M, N, K, lda, ldb, ldd, FA, FB, 12, clock_stamps, st);
+    return launch_w4(A, B, D, sa_inv, sb_inv, M, N, K, lda, ldb, ldd, FA, FB, variant, (algo == 8 || algo == 11) ? (void*)bias : nullptr, st);
+#ifdef MI_DIAG
+  } else if (algo >= 70 && algo <= 73 && !mx) {  // persistent four-wave kernel, epilogue store policy: 70 plain, 71 nt, 72 sc1 + nt; 73: per-K-tile stamps
+    return launch_w4(A, B, D, sa_inv, sb_inv, M, N, K, lda, ldb, ldd, FA, FB, algo - 56, algo == 73 ? (void*)bias : nullptr, st);
+  } else if (algo >= 50 && algo < 70 && !mx) {  // four-wave kernel schedule sweep: 50 + 4 S + {0: product, 1: no stores, 2: stamps}
+    return launch_w4(A, B, D, sa_inv, sb_inv, M, N, K, lda, ldb, ldd, FA, FB, algo - 30, (algo % 4) == 0 ? (void*)bias : nullptr, st);
   } else if (algo == 13 && !mx) {
     int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
     hipLaunchKernelGGL((gemm_256_8ph<FA, FB, OUT, 1>), dim3(tiles_m * tiles_n), dim3(512), 0, st, a, b, D, sa_inv, sb_inv,
@@ -1451,6 +1484,7 @@ static int launch_fmt(const void* A, const void* B, void* D, const float* sa_inv
     int tiles_m = (int)(M / BM), tiles_n = (int)(N / BN);
     hipLaunchKernelGGL((gemm_256_8ph<FA, FB, OUT, 2>), dim3(tiles_m * tiles_n), dim3(512), 0, st, a, b, D, sa_inv, sb_inv,
                        bp, (int)M, (int)N, (int)K, lda, ldb, ldd, tiles_m, tiles_n);
+#endif
   } else {
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
     if (mx)
@@ -1466,10 +1500,10 @@ static int launch_fmt(const void* A, const void* B, void* D, const float* sa_inv
 
 static int dispatch(const void* A, const void* B, void* D, const float* sa_inv, const float* sb_inv, const void* SA,
                     const void* SB, const void* bias, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb,
-                    int64_t ldd, int fa, int fb, int out, int algo, bool mx, hipStream_t st) {
+                    int64_t ldd, int fa, int fb, int out, int algo, bool mx, hipStream_t st, void* clock_stamps = nullptr) {
 #define MI_CASE(FA_, FB_, OUT_)                                                                               \
   if (fa == FA_ && fb == FB_ && out == OUT_)                                                                  \
-    return launch_fmt<FA_, FB_, OUT_>(A, B, D, sa_inv, sb_inv, SA, SB, bias, M, N, K, lda, ldb, ldd, algo, mx, st);
+    return launch_fmt<FA_, FB_, OUT_>(A, B, D, sa_inv, sb_inv, SA, SB, bias, M, N, K, lda, ldb, ldd, algo, mx, st, clock_stamps);
   MI_CASE(0, 0, 0) MI_CASE(0, 1, 0) MI_CASE(1, 0, 0) MI_CASE(1, 1, 0)
   MI_CASE(0, 0, 1) MI_CASE(0, 1, 1) MI_CASE(1, 0, 1) MI_CASE(1, 1, 1)
 #undef MI_CASE
@@ -1500,6 +1534,12 @@ static int pick_algo(int algo, int64_t M, int64_t N, int64_t K, int64_t lda, int
   const bool p8_ok = (M % 256 == 0 || M % 192 == 0) && (N % 256 == 0 || N % 192 == 0) && M > 0 && N > 0 && K > 0 &&
                      (K % (2 * BK) == 0) && out == 0 && M * lda < (1LL << 31) && N * ldb < (1LL << 31) &&
                      M * ldd * 2 < (1LL << 31);
+#ifndef MI_DIAG
+  if (algo == 7 || algo == 8 || (algo >= 10 && algo <= 30) || algo == 46 || (algo >= 50 && algo <= 73)) {
+    set_error("%s: algo %d is a timing / diagnostic build; it lives in the lab library (make -C llm_fp8_amd/csrc lab)", who, algo);
+    return MI_ERR_ARG;
+  }
+#endif
   if (algo == 4 || algo == 5 || (algo >= 15 && algo <= 30) || (algo >= 40 && algo <= 46)) {
     if (!p8_ok) {
       set_error("%s: algo %d needs M,N %% 256 (or 192) == 0, K %% 256 == 0, bf16 output, operands < 2 GiB", who, algo);
@@ -1507,12 +1547,20 @@ static int pick_algo(int algo, int64_t M, int64_t N, int64_t K, int64_t lda, int
     }
     return algo;
   }
-  if (algo >= 6 && algo <= 8) {
+  if ((algo >= 6 && algo <= 12) || (algo >= 50 && algo <= 73)) {
     if (!(p8_ok && M % 256 == 0 && N % 256 == 0)) {
       set_error("%s: algo %d needs M,N,K %% 256 == 0, bf16 output, operands < 2 GiB", who, algo);
       return MI_ERR_SHAPE;
     }
     return algo;
+  }
+  if (algo == 47) {
+    // auto, four-wave kernel where it is the faster one (measured, profiles/r03_w4p_*): no bias, 256-multiples, K >= 512, and the
+    // eight-wave kernel's own tile-shape choice is 256 x 256 (where it prefers 192-wide tiles the round count decides)
+    if (p8_ok && !has_bias && M % 256 == 0 && N % 256 == 0 && K >= 512 && pick_tile_cfg(M, N, K) == 0 &&
+        ((M / 256) * (N / 256) + num_cus() - 1) / num_cus() <= 64)
+      return 9;
+    algo = 0;
   }
   if (algo == 0) return p8_ok ? 4 : (fast_ok ? 3 : 1);
   if (algo == 1) return 1;
@@ -1542,6 +1590,24 @@ extern "C" int mi_gemm_fp8(const void* A, const void* B, void* D, const float* s
                       out_dtype, a, false, (hipStream_t)stream);
 }
 
+extern "C" int mi_gemm_fp8_clock(const void* A, const void* B, void* D, const float* sa_inv, const float* sb_inv, int64_t M,
+                                 int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int algo, unsigned long long* stamps,
+                                 void* stream) {
+  int rc = mi::check_common("mi_gemm_fp8_clock", A, B, D, M, N, K, lda, ldb, ldd, 0, 0, 0);
+  if (rc != MI_OK) return rc;
+  MI_CHECK_ARG(sa_inv && sb_inv && stamps, "mi_gemm_fp8_clock: null pointer");
+  MI_CHECK_ARG(algo == 0 || algo == 4 || algo == 9, "mi_gemm_fp8_clock: algo must be 0, 4 or 9");
+  if (M == 0 || N == 0) return MI_OK;
+  int a = mi::pick_algo(algo, M, N, K, lda, ldb, ldd, 0, false, "mi_gemm_fp8_clock");
+  if (a < 0) return a;
+  if (a != 4 && a != 9) {
+    mi::set_error("mi_gemm_fp8_clock: the shape does not run on a persistent kernel");
+    return MI_ERR_SHAPE;
+  }
+  return mi::dispatch(A, B, D, sa_inv, sb_inv, nullptr, nullptr, nullptr, M, N, K, lda, ldb, ldd, 0, 0, 0, a, false,
+                      (hipStream_t)stream, (void*)stamps);
+}
+
 extern "C" int mi_gemm_mxfp8(const void* A, const void* SA, const void* B, const void* SB, void* D,
                              const void* bias_bf16, int64_t M, int64_t N, int64_t K, int fmt_a, int fmt_b,
                              int out_dtype, int algo, void* stream) {
@@ -1549,7 +1615,11 @@ extern "C" int mi_gemm_mxfp8(const void* A, const void* SA, const void* B, const
   if (rc != MI_OK) return rc;
   MI_CHECK_ARG(SA && SB, "mi_gemm_mxfp8: null scale pointer");
   MI_CHECK_ARG(K % 32 == 0, "mi_gemm_mxfp8: K must be a multiple of 32");
+#ifdef MI_DIAG
   MI_CHECK_ARG(algo == 0 || algo == 1 || algo == 4 || algo == 5 || algo == 18 || algo == 19 || (algo >= 40 && algo <= 45), "mi_gemm_mxfp8: algo must be 0, 1, 4, 5, 18, 19 or 40-45");
+#else
+  MI_CHECK_ARG(algo == 0 || algo == 1 || algo == 4 || algo == 5 || (algo >= 40 && algo <= 45), "mi_gemm_mxfp8: algo must be 0, 1, 4, 5 or 40-45");
+#endif
   if (M == 0 || N == 0) return MI_OK;
   int a = algo == 0 ? 4 : algo;
   if (a != 1) {

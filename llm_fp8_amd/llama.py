@@ -240,8 +240,12 @@ class TELlamaForCausalLM:
         return model
 
 
-def replace_params(hf_state_dict, te_state_dict, config):
-    """HF -> TE-named parameters, same mapping as te_llama.py:181-239 (q|k|v separate, gate|up stacked)."""
+def replace_params(hf_state_dict, te_state_dict, config, written: Optional[set] = None):
+    """HF -> TE-named parameters, same mapping as te_llama.py:181-239 (q|k|v separate, gate|up stacked).  The copies go through
+    `Tensor.copy_` on the state-dict tensors (which share the parameters' version counters) and not through `.data[:] = ...` as in
+    the reference: a `.data` write leaves `Parameter._version` where it was, and the FP8 weight copies the optimiser keeps
+    (module.WeightSink / MXWeightSink) are declared current by exactly that counter -- a checkpoint loaded into a model that has
+    already stepped would otherwise keep running on the FP8 images of the old weights.  `written` collects the TE keys filled."""
     prefixes = set()
     for k in hf_state_dict.keys():
         m = re.match(r"model\.layers\.\d+\.", k)
@@ -257,14 +261,21 @@ def replace_params(hf_state_dict, te_state_dict, config):
         "mlp.down_proj.weight": "layernorm_mlp.fc2_weight",
     }
     f = config.intermediate_size
-    for p in prefixes:
-        for src, dst in simple.items():
-            if p + src in hf_state_dict:
-                te_state_dict[p + dst].data[:] = hf_state_dict[p + src].data[:]
-        if p + "mlp.gate_proj.weight" in hf_state_dict:
-            te_state_dict[p + "layernorm_mlp.fc1_weight"].data[:f] = hf_state_dict[p + "mlp.gate_proj.weight"].data
-        if p + "mlp.up_proj.weight" in hf_state_dict:
-            te_state_dict[p + "layernorm_mlp.fc1_weight"].data[f:] = hf_state_dict[p + "mlp.up_proj.weight"].data
+    with torch.no_grad():
+        for p in prefixes:
+            for src, dst in simple.items():
+                if p + src in hf_state_dict:
+                    te_state_dict[p + dst].copy_(hf_state_dict[p + src])
+                    if written is not None:
+                        written.add(p + dst)
+            if p + "mlp.gate_proj.weight" in hf_state_dict:
+                te_state_dict[p + "layernorm_mlp.fc1_weight"][:f].copy_(hf_state_dict[p + "mlp.gate_proj.weight"])
+                if written is not None:
+                    written.add(p + "layernorm_mlp.fc1_weight#gate")
+            if p + "mlp.up_proj.weight" in hf_state_dict:
+                te_state_dict[p + "layernorm_mlp.fc1_weight"][f:].copy_(hf_state_dict[p + "mlp.up_proj.weight"])
+                if written is not None:
+                    written.add(p + "layernorm_mlp.fc1_weight#up")
     return prefixes
 
 

@@ -293,13 +293,14 @@ def _wgrad_out(weights, K: int) -> Optional[torch.Tensor]:
 
 def _dgrad_wgrad(g8, wt8, g8t, xt8, sig, si_w, si_x, fmt_b: int, fmt_f: int, dw_out, need_dgrad: bool, need_wgrad: bool):
     """A Linear's two backward GEMMs on one grad_output: dX [M, K] = G8 [M, N] . W8T [K, N]^T and dW [N, K] = G8T [N, M] . X8T [K, M]^T.
-    ONE grouped persistent launch (ops.gemm_fp8_grouped) where it measures faster (ops.grouped_gemm_autotune, once per shape) --
+    ONE grouped persistent launch (ops.gemm_fp8_grouped) where that is faster (ops.grouped_gemm_choice: measured once per shape in
+    a single-process run, the count model under torch.distributed; env LLM_FP8_AMD_GROUPED_GEMM = auto | plan | autotune | off) --
     one ramp, one exposed epilogue, and the short problem's tiles fill the idle part of the long one's last round -- else two
     launches.  Bitwise the
     same results either way.  (Under torch.distributed the GEMMs run one workgroup per tile so that RCCL's kernels get CUs:
     no persistent grouping there.)"""
     dx = dw = None
-    if need_dgrad and need_wgrad and ops.default_gemm_algo() in (0, 4) and os.environ.get("LLM_FP8_AMD_NO_GROUPED_GEMM") != "1":
+    if need_dgrad and need_wgrad and ops.default_gemm_algo() in (0, 4, 47) and os.environ.get("LLM_FP8_AMD_NO_GROUPED_GEMM") != "1":
         M, N = g8.shape
         K = wt8.shape[0]
         if (ops.grouped_gemm_ok(((M, K, N), (N, K, M))) and g8.stride(1) == 1 and wt8.stride(1) == 1 and g8t.stride(1) == 1
@@ -307,7 +308,7 @@ def _dgrad_wgrad(g8, wt8, g8t, xt8, sig, si_w, si_x, fmt_b: int, fmt_f: int, dw_
             dx = torch.empty((M, K), dtype=torch.bfloat16, device=g8.device)
             dw = dw_out if dw_out is not None else torch.empty((N, K), dtype=torch.bfloat16, device=g8.device)
             probs = [(g8, wt8, sig, si_w, dx), (g8t, xt8, sig, si_x, dw)]
-            cfg = ops.grouped_gemm_autotune(probs, fmt_b, fmt_f)  # measured once per shape: -1 = two launches are faster here
+            cfg = ops.grouped_gemm_choice(probs, fmt_b, fmt_f)  # cached per shape set: -1 = two launches are faster here
             if cfg >= 0:
                 ops.gemm_fp8_grouped(probs, fmt_b, fmt_f, tile_cfg=cfg)
                 return dx, dw

@@ -45,7 +45,7 @@ def default_gemm_algo() -> int:
     d = torch.distributed
     if d.is_available() and d.is_initialized() and d.get_world_size() > 1:
         return 5
-    return 0
+    return 47 if os.environ.get("LLM_FP8_AMD_GEMM_W4", "1") != "0" else 0
 
 
 def _stream() -> int:
@@ -157,6 +157,8 @@ def gemm_fp8(a8: torch.Tensor, b8: torch.Tensor, sa_inv: torch.Tensor, sb_inv: t
         algo = default_gemm_algo()
         M_, N_, K_ = a8.shape[0], b8.shape[0], a8.shape[1]
         if algo == 3 and (M_ % 256 or N_ % 256 or K_ % 128):
+            algo = 0
+        if algo == 47 and (out_dtype != torch.bfloat16 or (out is not None and out.dtype != torch.bfloat16)):
             algo = 0
         if algo == 5 and ((M_ % 256 and M_ % 192) or (N_ % 256 and N_ % 192) or K_ % 256 or out_dtype != torch.bfloat16
                           or (out is not None and out.dtype != torch.bfloat16)):
@@ -406,16 +408,41 @@ def grouped_gemm_plan(shapes, n_cu: int = 256) -> int:
 _GROUP_TUNED: dict = {}
 
 
+def grouped_gemm_choice(problems, fmt_a: int, fmt_b: int) -> int:
+    """-1 = launch a Linear's dgrad and wgrad separately, 0-3 = one grouped launch with that tile shape.  Policy
+    (env LLM_FP8_AMD_GROUPED_GEMM):
+      auto (default)  single process: `autotune` -- MEASURED once per (shapes, formats) the first time the shape set shows up, i.e.
+                      inside the first backward of a run: ~7 timed relaunches per candidate on SCRATCH outputs and one host
+                      synchronisation per candidate; every later step only reads the cache (no host sync).  Under torch.distributed:
+                      `plan`, so that every rank takes the same decision without timing anything between collectives.
+      plan            the count model (grouped_gemm_plan): no timing, no host sync, box-independent.
+      autotune        always measure (also under torch.distributed).
+      off             always two launches (same as LLM_FP8_AMD_NO_GROUPED_GEMM=1).
+    All choices give bitwise identical results."""
+    mode = os.environ.get("LLM_FP8_AMD_GROUPED_GEMM", "auto")
+    if mode == "off":
+        return -1
+    if mode == "auto":
+        import torch.distributed as dist
+        mode = "plan" if (dist.is_available() and dist.is_initialized()) else "autotune"
+    if mode == "plan":
+        return grouped_gemm_plan(tuple((a.shape[0], b.shape[0], a.shape[1]) for a, b, _, _, _ in problems))
+    if mode != "autotune":
+        raise ValueError(f"LLM_FP8_AMD_GROUPED_GEMM={mode!r}: expected auto, plan, autotune or off")
+    return grouped_gemm_autotune(problems, fmt_a, fmt_b)
+
+
 def grouped_gemm_autotune(problems, fmt_a: int, fmt_b: int, iters: int = 3) -> int:
     """Measured choice for a recurring group of GEMMs (a Linear's dgrad + wgrad): -1 = separate launches, 0-3 = one grouped launch
-    with that tile shape.  Timed once per (shapes, formats) on the operands at hand -- every candidate writes bitwise the same
-    outputs, so re-running them is harmless -- and cached.  The model (grouped_gemm_plan) ranks the same candidates from counts
-    alone; the measurement also sees what the model leaves out (per-tile epilogue cost, L2 behaviour, clock)."""
+    with that tile shape.  Timed once per (shapes, formats) on the operands at hand but into SCRATCH outputs (the live dX buffer and
+    gradient-arena slot are not touched), and cached.  The model (grouped_gemm_plan) ranks the same candidates from counts alone;
+    the measurement also sees what the model leaves out (per-tile epilogue cost, L2 behaviour, clock)."""
     shapes = tuple((a.shape[0], b.shape[0], a.shape[1]) for a, b, _, _, _ in problems)
     key = (shapes, fmt_a, fmt_b)
     hit = _GROUP_TUNED.get(key)
     if hit is not None:
         return hit
+    problems = [(a8, b8, sa, sb, torch.empty_like(out)) for a8, b8, sa, sb, out in problems]
     cands = {-1: None}
     if grouped_gemm_ok(shapes):
         for cfg, (bm, bn) in enumerate(_TILE_CFGS):

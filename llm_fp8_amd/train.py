@@ -39,7 +39,7 @@ class TrainingConfig:
     num_training_steps: int = 1000
     gradient_accumulation_steps: int = 1
     max_grad_norm: float = 1.0
-    sharding_mode: str = "auto"           # "auto" | "replicated" | "ddp" | "fsdp_full" | "none"
+    sharding_mode: str = "auto"           # one of SHARDING_MODES
     seed: int = 42
     num_hidden_layers: Optional[int] = None  # override for small tests only
     vocab_size: Optional[int] = None
@@ -111,6 +111,12 @@ def prepare_model(model: torch.nn.Module, cfg: TrainingConfig) -> torch.nn.Modul
     return model
 
 
+# auto: replicated (gradient arena) while the replicated training state fits the device, else fsdp_fp8; replicated:
+# distributed.GradArenaDP; fsdp_fp8: distributed.ShardedFP8DP (FULL_SHARD counterpart with FP8 all-gather); fsdp_full / ddp: the
+# torch wrappers the reference uses (train_multi_gpu.py:414-445, :447-470); none: no wrapper
+SHARDING_MODES = ("auto", "replicated", "fsdp_fp8", "fsdp_full", "ddp", "none")
+
+
 def resolve_sharding_mode(mode: str, model: torch.nn.Module, device) -> str:
     """`auto` (DistributedConfig._auto_detect_sharding, train_multi_gpu.py:137-146, picks FSDP FULL_SHARD whenever there is
     more than one GPU): here the run shards only when it has to -- the replicated state of every BASELINE.json model fits
@@ -164,7 +170,7 @@ def wrap_distributed(model: torch.nn.Module, cfg: TrainingConfig, device) -> tor
                     backward_prefetch=BackwardPrefetch.BACKWARD_PRE, forward_prefetch=True, limit_all_gathers=True,
                     use_orig_params=True, sync_module_states=True,
                     device_id=device if device.type == "cuda" else None)
-    raise ValueError(f"unsupported sharding_mode {cfg.sharding_mode!r}")
+    raise ValueError(f"unsupported sharding_mode {cfg.sharding_mode!r} (one of {SHARDING_MODES})")
 
 
 def create_optimizer(model, cfg: TrainingConfig):
@@ -280,7 +286,7 @@ def main(argv=None):
     ap.add_argument("--mixed_precision", choices=["bf16", "fp8"], default="fp8")
     ap.add_argument("--fp8_scenario", choices=["default", "hybrid", "mxfp8"], default="default")
     ap.add_argument("--use_te", action="store_true")
-    ap.add_argument("--sharding_mode", default="auto")
+    ap.add_argument("--sharding_mode", choices=SHARDING_MODES, default="auto")
     ap.add_argument("--num_steps", type=int, default=10)
     ap.add_argument("--learning_rate", type=float, default=1.41e-5)
     ap.add_argument("--num_hidden_layers", type=int, default=None)

@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     src = open(os.path.join(ROOT, "include", "mi_fp8.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"#ifdef MI_DIAG.*?#endif", "", src, flags=re.S)   # lab-build-only declarations
     return sorted(set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", src)))
 
 
@@ -40,6 +41,21 @@ def test_abi_version_is_one_number_in_header_library_and_binding():
     m = re.search(r"#define\s+MI_ABI_VERSION\s+(\d+)", src)
     assert m is not None
     assert int(m.group(1)) == _lib.load().mi_abi_version() == _lib.ABI_VERSION >= 2
+
+
+def test_product_library_has_no_lab_surface():
+    """Round-2 verdict: product ABI and lab bench were one surface.  The timing / ablation / stamp builds now live in
+    tools/bin/libmi_fp8_lab.so (-DMI_DIAG); the shipped library neither exports mi_attn_fwd_diag nor accepts a diagnostic algo."""
+    from llm_fp8_amd import _lib
+    lib = _lib.load()
+    assert not hasattr(lib, "mi_attn_fwd_diag")
+    fake = 0x10000  # non-null, 16-byte aligned; the algo is rejected before anything is launched or dereferenced
+    for algo in (7, 8, 10, 11, 12, 13, 14, 15, 20, 21, 22, 27, 28, 29, 30, 46):
+        rc = lib.mi_gemm_fp8(fake, fake, fake, fake, fake, None, 256, 256, 256, 256, 256, 256, 0, 0, 0, algo, None)
+        assert rc == -1 and b"lab library" in lib.mi_last_error(), algo
+    for algo in (18, 19):
+        rc = lib.mi_gemm_mxfp8(fake, fake, fake, fake, fake, None, 256, 256, 256, 0, 0, 0, algo, None)
+        assert rc == -1
 
 
 def test_argument_errors_are_reported_not_thrown():

@@ -1,5 +1,7 @@
 """GPU parity tests: every HIP kernel behind the C ABI against the CPU oracle.
 Casts / scales / MX bytes: bit-exact.  GEMMs: |d| <= 2^-7 |ref| + 1e-3 rms(ref)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -163,9 +165,11 @@ GEMM_SHAPES = [(256, 256, 256), (512, 768, 640), (768, 384, 512), (1536, 1920, 2
 
 @pytest.mark.parametrize("shape", GEMM_SHAPES)
 @pytest.mark.parametrize("fa,fb", [(O.E4M3, O.E4M3), (O.E5M2, O.E4M3), (O.E4M3, O.E5M2), (O.E5M2, O.E5M2)])
-@pytest.mark.parametrize("algo", [0, 1, 2, 3, 4, 5, 41, 42, 43])
+@pytest.mark.parametrize("algo", [0, 1, 2, 3, 4, 5, 6, 9, 41, 42, 43])
 def test_gemm_fp8_vs_oracle(ops, dev, shape, fa, fb, algo):
     M, N, K = shape
+    if algo in (6, 9) and (M % 256 or N % 256 or K % 256 or (algo == 9 and K < 512)):
+        pytest.skip("four-wave kernels need 256-aligned M, N, K (the persistent one K >= 512)")
     if algo == 1 and M * N * K > 256 * 512 * 3072:
         pytest.skip("generic path covered at smaller sizes")
     if algo in (2, 3) and (M % 256 or N % 256 or K % 128):
@@ -181,7 +185,7 @@ def test_gemm_fp8_vs_oracle(ops, dev, shape, fa, fb, algo):
     sa, sb = np.float32(1 / 7.3), np.float32(1 / 0.011)
     rng = np.random.default_rng(3)
     bias = O.f32_to_bf16_bits(rng.normal(size=N).astype(np.float32) * 10)
-    for use_bias in (False, True):
+    for use_bias in ((False,) if algo in (6, 9) else (False, True)):  # the four-wave kernels take no bias
         ref = O.gemm_fp8_tn(a8, b8, fa, fb, sa, sb, bias if use_bias else None, out_f32=True)
         d = ops.gemm_fp8(torch.from_numpy(a8).to(dev), torch.from_numpy(b8).to(dev), _f32(sa, dev), _f32(sb, dev),
                          fa, fb, bias=bits_to_bf16(bias, dev) if use_bias else None, algo=algo)
@@ -789,23 +793,63 @@ def test_persistent_gemm_bitwise_reproducible_under_load(ops, dev, mx, shape):
         assert torch.equal(run(), ref)
 
 
-@pytest.mark.parametrize("shape", [(2048, 4096, 512), (8192, 3072, 1024), (3072, 3072, 768), (768, 3072, 1280)])
-@pytest.mark.parametrize("algo", [27, 29, 46])
-def test_epilogue_placement_builds_are_bitwise_the_default(ops, dev, shape, algo):
-    """The timing builds that move the epilogue (27: woven into the MFMA segments, 29: conversion woven / stores one load segment
-    later, 46: block epilogue after each tile) compute the same fp32 sums in the same order as the default placement: any
-    difference means a quadrant was converted after its registers were reused, or a counted vmcnt wait let a store's data or
-    an LDS tile be overwritten early.  Shapes: 2 - 8 tiles per workgroup on all four tile shapes, K = 512 .. 1280."""
+@pytest.mark.parametrize("shape", [(2048, 4096, 512), (8192, 3072, 1024), (3072, 3072, 768), (768, 3072, 1280), (8192, 8192, 256),
+                                   (4352, 4096, 256), (256, 256, 256), (8192, 5120, 3072)])
+@pytest.mark.parametrize("algo", [6, 9])
+@pytest.mark.parametrize("fa,fb", [(O.E4M3, O.E4M3), (O.E5M2, O.E4M3), (O.E4M3, O.E5M2)])
+def test_four_wave_kernels_are_bitwise_the_eight_wave_kernel(ops, dev, shape, algo, fa, fb):
+    """mi_gemm_w4.hip (algo 6: one tile per workgroup, algo 9: persistent with the epilogue spread over the tile boundary) computes
+    every output element with the same MFMA sequence over K as the eight-wave persistent kernel (algo 4): the results must be
+    IDENTICAL bits.  Any difference means an accumulator was read after the next tile's zero-C MFMA overwrote it, a counted vmcnt
+    wait let an LDS half or a store's data be reused early, or a cursor staged the wrong panel.  Shapes: 1 - 4 tiles per workgroup,
+    K-tile counts 2 (the combined LAST2 K-tile), 4, 6, 8, 10 and 24, tile counts that are not a multiple of the CU count."""
     M, N, K = shape
-    g = torch.Generator(device=dev).manual_seed(11)
+    if M % 256 or N % 256 or K % 256 or (algo == 9 and K < 512):
+        pytest.skip("the four-wave kernels take 256-multiples only (the persistent one K >= 512)")
+    g = torch.Generator(device=dev).manual_seed(11 + fa)
     a = torch.randint(0, 256, (M, K), generator=g, device=dev, dtype=torch.uint8)
     b = torch.randint(0, 256, (N, K), generator=g, device=dev, dtype=torch.uint8)
-    for t in (a, b):
-        t[(t & 0x7F) >= 0x78] &= 0x3F
+    for t, f in ((a, fa), (b, fb)):
+        if f == O.E4M3:
+            t[(t & 0x7F) >= 0x78] &= 0x3F
+        else:
+            t[(t & 0x7F) >= 0x54] &= 0xCF
     sa, sb = torch.full((1,), 0.37, device=dev), torch.full((1,), 1.9, device=dev)
-    ref = ops.gemm_fp8(a, b, sa, sb, 0, 0, algo=4)
+    ref = ops.gemm_fp8(a, b, sa, sb, fa, fb, algo=4 if (M % 256 == 0 and N % 256 == 0) else 0)
+    ref40 = ops.gemm_fp8(a, b, sa, sb, fa, fb, algo=40)  # the 256 x 256 shape of the eight-wave kernel, whatever the picker takes
+    assert torch.equal(ref, ref40)
     for _ in range(3):
-        assert torch.equal(ops.gemm_fp8(a, b, sa, sb, 0, 0, algo=algo), ref)
+        assert torch.equal(ops.gemm_fp8(a, b, sa, sb, fa, fb, algo=algo), ref)
+
+
+def test_lab_timing_builds_are_bitwise_the_default(dev):
+    """The lab library's epilogue-placement builds (27, 29, 46) and phase schedules of the four-wave kernel (54, 62, 66) move work
+    around but keep every fp32 summation order: same bits as the product kernel.  Skipped when the lab library is not built
+    (tools/bin/libmi_fp8_lab.so; `make -C llm_fp8_amd/csrc lab`).  The lab library is loaded directly -- the package never does."""
+    import ctypes
+    from llm_fp8_amd import _lib
+    if not os.path.exists(_lib.LAB_LIB_PATH):
+        pytest.skip("lab library not built")
+    lab = ctypes.CDLL(_lib.LAB_LIB_PATH)
+    lab.mi_gemm_fp8.argtypes = _lib.SIGNATURES["mi_gemm_fp8"]
+    lab.mi_gemm_fp8.restype = ctypes.c_int
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=dev).manual_seed(11)
+    for (M, N, K) in ((2048, 4096, 512), (8192, 3072, 1024), (3072, 3072, 768), (768, 3072, 1280)):
+        a = torch.randint(0, 256, (M, K), generator=g, device=dev, dtype=torch.uint8)
+        b = torch.randint(0, 256, (N, K), generator=g, device=dev, dtype=torch.uint8)
+        for t in (a, b):
+            t[(t & 0x7F) >= 0x78] &= 0x3F
+        sa, sb = torch.full((1,), 0.37, device=dev), torch.full((1,), 1.9, device=dev)
+        outs = {}
+        for algo in (4, 27, 29, 46) + ((54, 62, 66) if M % 256 == 0 and N % 256 == 0 and K % 256 == 0 else ()):
+            out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+            rc = lab.mi_gemm_fp8(a.data_ptr(), b.data_ptr(), out.data_ptr(), sa.data_ptr(), sb.data_ptr(), None, M, N, K, K, K, N, 0, 0, 0, algo, st)
+            assert rc == 0, f"algo {algo}: {lab.mi_last_error()}"
+            outs[algo] = out
+        torch.cuda.synchronize()
+        for algo, out in outs.items():
+            assert torch.equal(out, outs[4]), f"lab algo {algo} differs from algo 4 on {M}x{N}x{K}"
 
 
 @pytest.mark.parametrize("fmt", [O.E4M3, O.E5M2])

@@ -7,6 +7,8 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from llm_fp8_amd import _lib as _mi_lib  # noqa: E402
+_mi_lib.use_lab_library()  # timing / ablation builds live in tools/bin/libmi_fp8_lab.so (make -C llm_fp8_amd/csrc lab)
 from llm_fp8_amd.pytorch import ops  # noqa: E402
 
 SHAPES_3B = {"qkv": (8192, 5120, 3072), "o": (8192, 3072, 3072), "fc1": (8192, 16384, 3072), "fc2": (8192, 3072, 8192)}

@@ -12,6 +12,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from llm_fp8_amd import _lib  # noqa: E402
+from llm_fp8_amd import _lib as _mi_lib  # noqa: E402
+_mi_lib.use_lab_library()  # timing / ablation builds live in tools/bin/libmi_fp8_lab.so (make -C llm_fp8_amd/csrc lab)
 from llm_fp8_amd.pytorch import ops  # noqa: E402
 from tools.bench_kernels import rand_fp8, time_interleaved  # noqa: E402
 
@@ -40,7 +42,9 @@ def main():
     shapes = [s for s in shapes_3b() if not args.sites or s[0].split(".")[0] in args.sites.split(",")]
     if "parity" in args.which:
         sc = torch.tensor([0.37], device=dev)
-        for name, m, n, k in shapes + [("small", 512, 768, 256), ("small2", 256, 256, 512), ("tall", 2048, 256, 1024)]:
+        extra = [("small", 512, 768, 512), ("small2", 256, 256, 512), ("tall", 2048, 256, 1024), ("one", 256, 256, 768),
+                 ("nk4x4", 8192, 8192, 512), ("nk6odd", 4096, 4352, 768), ("nk8odd", 4352, 4096, 1024), ("nk10", 2048, 4096, 1280)]
+        for name, m, n, k in shapes + extra:
             a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
             ref = ops.gemm_fp8(a, b, sc, one, 0, 0, algo=4)
             for al in [int(x) for x in args.parity_algos.split(",")]:
@@ -63,12 +67,51 @@ def main():
                 tot[al] += res[al]
             print(f"timing {name:10s} {m}x{n}x{k}: " + "  ".join(f"a{al}: {t*1e6:7.1f} us {2.0*m*n*k/t/1e12:5.0f} TF" for al, t in res.items()), flush=True)
         print("timing total: " + "  ".join(f"a{al}: {t*1e6:8.1f} us" for al, t in tot.items()), flush=True)
+    if "sched" in args.which:  # phase schedules of the one-tile-per-workgroup kernel (mi_gemm_w4.hip w4::sched_*): 50 + 4 S + kind
+        scheds = {"S0": (6, 7, 8), "S1": (54, 55, 56), "S3": (62, 63, 64), "S4": (66, 67, 68)}
+        import time
+        for name, m, n, k in shapes:
+            a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
+            out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+            ref = ops.gemm_fp8(a, b, one, one, 0, 0, algo=4)
+            for sn, (prod, nost, stamp) in scheds.items():
+                assert torch.equal(ref, ops.gemm_fp8(a, b, one, one, 0, 0, algo=prod)), f"schedule {sn} differs from algo 4 on {name}"
+            res = time_interleaved({sn: (lambda al=v[1]: ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=al)) for sn, v in scheds.items()}, rounds=8, inner=5)
+            line = f"sched {name:10s} {m}x{n}x{k} (no stores): " + "  ".join(f"{sn}: {t*1e6:7.1f} us" for sn, t in res.items())
+            cyc = {}
+            for sn, (prod, nost, stamp) in scheds.items():
+                dbg = torch.zeros(((m // 256) * (n // 256), 4), dtype=torch.int64, device=dev)
+                for _ in range(60):
+                    ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=nost)
+                rc = lib.mi_gemm_fp8(a.data_ptr(), b.data_ptr(), out.data_ptr(), one.data_ptr(), one.data_ptr(), dbg.data_ptr(), m, n, k, k, k, n, 0, 0, 0, stamp, st)
+                assert rc == 0, lib.mi_last_error()
+                torch.cuda.synchronize()
+                d = dbg.cpu().double()
+                cyc[sn] = float((d[:, 0] / d[:, 2]).median())
+            print(line + "   loop cycles/K-tile: " + "  ".join(f"{sn}: {c:6.0f}" for sn, c in cyc.items()), flush=True)
+    if "ktstamps" in args.which:  # per-K-tile timeline of workgroup 0 of the persistent four-wave kernel (algo 73)
+        for name, m, n, k in shapes:
+            a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
+            out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+            dbg = torch.zeros(1024, dtype=torch.int64, device=dev)
+            for _ in range(100):
+                ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=9)
+            rc = lib.mi_gemm_fp8(a.data_ptr(), b.data_ptr(), out.data_ptr(), one.data_ptr(), one.data_ptr(), dbg.data_ptr(), m, n, k, k, k, n, 0, 0, 0, 73, st)
+            assert rc == 0, lib.mi_last_error()
+            torch.cuda.synchronize()
+            t = dbg.cpu().numpy()
+            t = t[t > 0]
+            d = (t[1:] - t[:-1])
+            nk = k // 128
+            print(f"ktstamps {name} {m}x{n}x{k}: nk {nk}, {len(d)} K-tiles; cycles per K-tile (rows = tiles):", flush=True)
+            for ti in range(0, len(d), nk):
+                print("   " + " ".join(f"{int(x):5d}" for x in d[ti:ti + nk]), flush=True)
     if "clock" in args.which:
         import time
         for name, m, n, k in shapes:
             a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
             out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
-            for label, heat, stamped, width in (("8ph", 13, 14, 2), ("w4 ", 7, 8, 4)):
+            for label, heat, stamped, width in (("8ph ", 13, 14, 2), ("w4  ", 7, 8, 4), ("p8  ", 4, 21, 4), ("w4p ", 9, 11, 4)):
                 ntiles = (m // 256) * (n // 256)
                 dbg = torch.zeros((ntiles, width), dtype=torch.int64, device=dev)
 
@@ -86,7 +129,7 @@ def main():
                 d = dbg.cpu().double()
                 d = d[d[:, 1] > 0]
                 clk = d[:, 0] / d[:, 1] * 100.0
-                cyc = d[:, 0] / (k / 128)
+                cyc = d[:, 0] / (d[:, 2] if width == 4 else (k / 128))
                 print(f"clock {name:10s} {label}: clock median {float(clk.median()):7.1f} MHz  loop cycles/K-tile median {float(cyc.median()):7.1f} "
                       f"(min {float(cyc.min()):.0f} max {float(cyc.max()):.0f}; 2048 = MFMA-bound)", flush=True)
 
