@@ -155,22 +155,27 @@ def gemm_clock_probe(sites, top: int = 4):
 
 
 def pmc_traffic(by_tag):
-    """Per-launch fabric bytes of the GEMM kernel from the committed rocprofv3 PMC passes (profiles/), averaged over the
-    launch mix of this run; shapes without a PMC row (lm_head) are left out of the average."""
+    """Per-launch fabric bytes of the GEMM launches from the committed rocprofv3 PMC passes (profiles/), averaged over the launch
+    mix of this run, TOGETHER with the algorithmic bytes of the same launches: (traffic, algorithmic, coverage, note).  A launch
+    tag without a PMC row is left out of BOTH averages; `coverage` = the share of this run's launches that has a row."""
     cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_gemm_pmc_traffic.json"))
     if not cands:
-        return None, "no PMC file"
+        return None, None, 0.0, "no PMC file"
     path = os.path.join(ROOT, "profiles", cands[-1])  # newest round
     tab = json.load(open(path))["sites"]
-    num = den = 0.0
+    num = alg = den = tot = 0.0
     for tag, v in by_tag.items():
+        tot += v["launches"]
         if tag in tab:
             num += v["launches"] * (tab[tag]["fabric_read_bytes"] + tab[tag]["fabric_write_bytes"])
+            alg += v["launches"] * tab[tag]["algorithmic_bytes"]
             den += v["launches"]
     if den == 0:
-        return None, "no measured shape in this run"
-    return num / den, ("avg bytes per launch over the decoder GEMM sites, rocprofv3 --pmc FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, "
-                       f"separate passes (profiles/{cands[-1]}); counts Infinity-Cache hits, i.e. L2-miss traffic")
+        return None, None, 0.0, "no measured shape in this run"
+    return num / den, alg / den, den / tot, (
+        "avg bytes per launch over the launches of this run that have a PMC row (forward sites, grouped dgrad + wgrad launches, lm_head), "
+        "rocprofv3 --pmc FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, separate passes "
+        f"(profiles/{cands[-1]}); counts Infinity-Cache hits, i.e. L2-miss traffic; `avg_algorithmic_bytes_per_launch` covers the SAME launches")
 
 
 def main():
@@ -182,7 +187,9 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--scenario", default="default", choices=["default", "hybrid", "mxfp8"])
-    ap.add_argument("--sharding_mode", default="auto")
+    ap.add_argument("--sharding_mode", default="auto", choices=["auto", "replicated", "fsdp_fp8", "fsdp_full", "ddp", "none"],
+                    help="BASELINE config #5 (Llama-3.1-8B, FSDP full shard over 8 GPUs) = "
+                         "`torchrun --nproc-per-node 8 bench.py --gpus 8 --model llama-3.1-8b --batch 12 --sharding_mode fsdp_fp8`")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result is then not the headline metric)")
     ap.add_argument("--route", default="fused", choices=["fused", "reference"],
                     help="reference = drive every decoder layer exactly as te_llama.py:76-81 does (public kwargs, plain residual adds)")
@@ -266,7 +273,10 @@ def main():
                                      "random-init weights, synthetic tokens"),
                        "route": args.route, "global_batch": args.batch * world, "seq_len": args.seq,
                        "parallelism": "single" if resolved_mode == "none" else
-                       f"dp{world} {resolved_mode}" + (" (gradient arena, bucketed RCCL all-reduce)" if resolved_mode == "replicated" else "")},
+                       f"dp{world} {resolved_mode}" + (" (gradient arena, bucketed RCCL all-reduce)" if resolved_mode == "replicated" else
+                                                       " (full shard: bf16 master rows, gradients, AdamW moments 1/N per rank; FP8 all-gather)" if resolved_mode == "fsdp_fp8" else ""),
+                       "config5_command": "python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 bench.py --gpus 8 "
+                                          "--model llama-3.1-8b --batch 12 --sharding_mode fsdp_fp8"},
             "final_loss": loss_val,
         }
         if not args.no_kernel_timing:
@@ -275,10 +285,11 @@ def main():
             g = summ.get(kind)
             if g and g["seconds"] > 0:
                 achieved = g["work"] / g["seconds"] / 1e12
-                traffic, traffic_note = pmc_traffic(g["by_tag"])
+                traffic, alg_bytes, coverage, traffic_note = pmc_traffic(g["by_tag"])
                 out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": FP8_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": achieved / FP8_DENSE_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
-                                   "avg_algorithmic_bytes_per_launch": g["bytes"] / g["launches"],
+                                   "avg_algorithmic_bytes_per_launch": alg_bytes if alg_bytes is not None else g["bytes"] / g["launches"],
+                                   "traffic_launch_coverage": coverage,
                                    "kernel": kind, "launches": g["launches"],
                                    "avg_launch_us": g["seconds"] / g["launches"] * 1e6,
                                    "avg_flop_per_launch": g["work"] / g["launches"],

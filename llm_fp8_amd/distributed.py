@@ -296,144 +296,328 @@ class GradArenaDP(torch.nn.Module):
                 "world": self.world}
 
 
+class _ShardHandle:
+    """What a module sees of a row-sharded weight (`Parameter._mi_sharded`): the wrapper, this rank's shard, its rows."""
+    __slots__ = ("dp", "shard", "r0", "rows")
+
+    def __init__(self, dp, shard, r0, rows):
+        self.dp, self.shard, self.r0, self.rows = dp, shard, r0, rows
+
+
 class ShardedFP8DP(GradArenaDP):
-    """The FSDP-full-shard counterpart with an FP8 all-gather (`--sharding_mode fsdp_fp8`).
+    """The FSDP FULL_SHARD counterpart with an FP8 all-gather (`--sharding_mode fsdp_fp8`).
 
-    torch's FSDP, as the reference wraps it (train_multi_gpu.py:414-445), all-gathers every layer's bf16 flat parameter in the
-    forward AND again in the backward and reduce-scatters bf16 gradients: 6 bytes per parameter and step over xGMI, plus a cast
-    of every weight after every gather.  The FP8 Linear needs none of the bf16 weights in its backward -- it saved w8T -- so:
+    torch's FSDP, as the reference wraps it (train_multi_gpu.py:392-406, :414-445), keeps parameters, gradients and optimiser
+    state at 1/world per rank, all-gathers every layer's bf16 flat parameter in the forward AND again in the backward and
+    reduce-scatters bf16 gradients: 6 bytes per parameter and step over xGMI, plus a cast of every weight after every gather.
+    The FP8 Linear needs none of the bf16 weights in its backward -- it saved w8T -- so here:
 
-      * every GEMM weight is ROW-sharded over the ranks (a [N, K] row-major weight cut into `world` equal row blocks = equal
-        contiguous flat chunks).  A rank keeps the AdamW moments of its rows only and updates those rows only;
-      * backward: the wgrad of a sharded weight is reduce-scattered (AVG) as soon as it is complete -- 2 bytes per parameter;
-        every other parameter (norms, biases, embedding tables) is small or needed in bf16 everywhere and goes through the
-        bucketed all-reduce of the base class;
-      * optimiser: ClippedAdamW on the shards; mi_adamw_cast_bf16_multi quantises the updated rows on the fly (delayed scaling:
-        the scale of the next forward is already final) into the rank's rows of the operand's FP8 copy (module.WeightSink);
-      * after the step ONE all-gather per operand moves the FP8 rows -- 1 byte per parameter -- and a local byte transpose
-        (mi_transpose_u8) rebuilds w8T.  Forward and backward of the next step run entirely on these copies: no gather in the
-        backward, no cast after a gather.  3 bytes per parameter and step instead of 6.
+      * every GEMM weight is ROW-sharded over the ranks ([N, K] cut into `world` equal row blocks).  A rank holds the bf16
+        MASTER ROWS it owns and nothing else of the master: the module's Parameter keeps its logical shape (an expanded view of
+        one element, no storage) and carries `_mi_sharded`; AdamW moments and the persistent gradient exist for the shard only;
+      * backward: the wgrad GEMM writes the operand's full dW into a TRANSIENT buffer; when autograd hands it over it is
+        reduce-scattered (AVG) into the shard's gradient, several weights per NCCL group call (`bucket_mb`), and freed when the
+        collective has completed -- at most two buckets of full-size gradients exist at a time.  Every other parameter (norms,
+        biases, embedding tables) is small or needed in bf16 everywhere and goes through the bucketed all-reduce of the base class;
+      * optimiser: ClippedAdamW on the shards; mi_adamw_cast_bf16_multi / mi_adamw_mxcast_bf16_multi quantise the updated rows on
+        the fly into the rank's rows of the operand's FP8 copies (module.WeightSink / MXWeightSink);
+      * after the step the FP8 rows (+ E8M0 scales for MXFP8: both orientations) are all-gathered ASYNCHRONOUSLY on RCCL's stream,
+        operand by operand in next-forward order, one NCCL group call per module; the forward of a module waits (stream-side) for
+        ITS operands only and rebuilds w8T locally (mi_transpose_u8), so layer 0 computes while layer 27 is still gathering.
+        No gather in the backward, no cast after a gather: 3 bytes per parameter and step instead of 6 (delayed scaling);
+      * whenever a sink is not current -- first step, a scale-arena generation bump (per-layer autocast without an outer one),
+        a loaded checkpoint, an evaluation pass first -- the module asks `refresh_operand`: the local rows are quantised with the
+        CURRENT scale and gathered, which is what the replicated run's forward cast computes.  There is no stale-master path.
 
-    amax: a rank deposits the amax of ITS rows; the arenas' MAX all-reduce (fp8.MetaArena.reduce) makes it global before the
-    next scale update, exactly as for activations.  The bf16 master tensors stay allocated at full size (rows of other ranks go
-    stale; `gather_master_weights()` refreshes them for evaluation without FP8 or for a checkpoint).  MXFP8 has no sink (its
-    quantiser is a different kernel): such modules stay replicated.  Unmeasured on multi-GPU hardware (the driver alone runs
-    N > 1); rehearsed with 2 ranks sharing one GPU (tests/test_distributed_gpu.py) and at world size 1 over RCCL."""
+    What stays at full size per rank: the FP8 operand copies the GEMMs read (w8 + w8T, 2 bytes per parameter; for 8B: 16 GB of
+    288).  `describe()` reports the bytes per category; tests/fsdp_fp8_worker.py asserts masters + gradients + moments = 1/world.
+    amax: a rank deposits the amax of ITS rows; the arenas' MAX all-reduce makes it global before the next scale update, so the
+    recipe must have reduce_amax=True (checked).  `gather_master_weights()` materialises full bf16 masters (checkpoint,
+    FP8-off evaluation), `reshard()` drops them again.  Unmeasured on multi-GPU hardware (the driver alone runs N > 1);
+    rehearsed with 2 ranks sharing one GPU over gloo and at world size 1 over RCCL (tests/test_distributed_gpu.py)."""
 
+    def __init__(self, module: torch.nn.Module, process_group=None, bucket_mb: float = 256.0, broadcast: bool = True,
+                 sparse_embedding_grads: bool = True):
+        self._rs_bucket_bytes = int(bucket_mb * (1 << 20))
+        super().__init__(module, process_group, bucket_mb, broadcast, sparse_embedding_grads)
+        self._shard_now()
+
+    # ------------------------------------------------------------------------------------------------ construction
     def _prepare_sharding(self):
         from .pytorch.module import Linear, LayerNormLinear, LayerNormMLP
-        rank = dist.get_rank(self.group)
-        self.rank = rank
+        self.rank = dist.get_rank(self.group)
+        self._rs_pending: list = []     # (shard parameter, full gradient) of the open reduce-scatter bucket
+        self._rs_pending_bytes = 0
+        self._rs_inflight: list = []    # (works, [tensors kept alive], [(shard parameter, full gradient or None)])
+        self._gathers: Dict[int, tuple] = {}  # id(sink) -> (works, post-gather fix-ups, stamp as of quantisation)
+        self._materialised = False
         tables = {id(m.weight) for m in self.module.modules() if isinstance(m, torch.nn.Embedding)}
         self._sharded: Dict[int, torch.nn.Parameter] = {}
+        self._fp8_modules = []
         for m in self.module.modules():
             if isinstance(m, (Linear, LayerNormLinear, LayerNormMLP)):
+                self._fp8_modules.append(m)
                 for p in m._parameters.values():
                     if (p is not None and p.requires_grad and p.dim() == 2 and id(p) not in tables and p.dtype == torch.bfloat16
-                            and p.is_contiguous() and p.shape[0] % (8 * self.world) == 0 and p.shape[1] % 8 == 0):
+                            and p.is_contiguous() and p.shape[0] % (32 * self.world) == 0 and p.shape[1] % 32 == 0):
                         self._sharded[id(p)] = p
         self._shards: Dict[int, torch.nn.Parameter] = {}
+
+    def _build(self, groups, bucket_bytes: int):
+        # the gradient arena holds the REPLICATED parameters only: a sharded weight's gradient exists at shard size
+        rest = [[p for p in g if id(p) not in self._sharded] for g in groups]
+        super()._build([g for g in rest if g], bucket_bytes)
         for p in self._sharded.values():
-            n = p.shape[0] // self.world
-            r0 = rank * n
-            sp = torch.nn.Parameter(p.data[r0:r0 + n], requires_grad=True)  # aliases the rank's rows of the master weight
-            sp._mi_shard_grad = torch.zeros_like(sp)  # the reduce-scatter's output; becomes `.grad` when it has landed
-            sp._mi_shard_of = (p, r0, n)
-            self._shards[id(p)] = sp
+            p.register_post_accumulate_grad_hook(self._on_sharded_grad)
 
-    def _own_bucket(self, p) -> bool:
-        return id(p) in self._sharded
+    def _shard_now(self):
+        """Cut every sharded weight: keep this rank's rows in a Parameter of its own, release the full master."""
+        with torch.no_grad():
+            for p in self._sharded.values():
+                n = p.shape[0] // self.world
+                r0 = self.rank * n
+                sp = torch.nn.Parameter(p.data[r0:r0 + n].clone(), requires_grad=True)
+                sp._mi_shard_grad = torch.zeros_like(sp)  # the reduce-scatter's output; becomes `.grad` when it has landed
+                sp._mi_shard_of = (p, r0, n)
+                self._shards[id(p)] = sp
+                p._mi_sharded = _ShardHandle(self, sp, r0, n)
+                p._mi_full_shape = tuple(p.shape)
+                p.data = torch.zeros(1, dtype=p.dtype, device=p.device).expand(p.shape)  # logical shape, no storage
 
-    def _launch(self, b: _Bucket):
-        p = b.shard_of
-        if p is None:
-            return super()._launch(b)
+    # ------------------------------------------------------------------------------------------------ backward side
+    def wgrad_buffer(self, weights, K: int) -> Optional[torch.Tensor]:
+        """module._wgrad_out: destination of one operand's weight-gradient GEMM -- a transient [sum N_i, K] bf16 buffer (the
+        caching allocator hands the blocks of finished reduce-scatters back)."""
+        if any(w.grad is not None for w in weights) or any(w.dtype != torch.bfloat16 or w.shape[1] != K for w in weights):
+            return None
+        return torch.empty((sum(w.shape[0] for w in weights), K), dtype=torch.bfloat16, device=self._shards[id(weights[0])].device)
+
+    def _on_sharded_grad(self, p: torch.nn.Parameter):
+        if not self._callback_queued:
+            self._callback_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+        if not self._sync:
+            return  # gradient accumulation: the full-size gradient stays in `.grad` until the synchronising pass (as FSDP.no_sync)
+        g = p.grad
+        if not g.is_contiguous():
+            g = g.contiguous()
         sp = self._shards[id(p)]
-        full, out = p._mi_grad_buf, sp._mi_shard_grad
+        p.grad = None
+        self._rs_pending.append((sp, g))
+        self._rs_pending_bytes += g.numel() * g.element_size()
+        if self._rs_pending_bytes >= self._rs_bucket_bytes:
+            self._flush_reduce_scatters()
+
+    def _flush_reduce_scatters(self):
+        """One NCCL group call (or, on gloo / at world 1, the per-weight fallback) for the pending (shard, full gradient) pairs."""
+        pend, self._rs_pending, self._rs_pending_bytes = self._rs_pending, [], 0
+        if not pend:
+            return
+        # at most two buckets of transient full-size gradients: settle the bucket before the previous one
+        while len(self._rs_inflight) >= 2:
+            self._settle(self._rs_inflight.pop(0))
         if self.world == 1 and not _FORCE_COLLECTIVES:
-            out.copy_(full)
-            self._works.append((None, (p, sp, None), False))
+            for sp, g in pend:
+                sp._mi_shard_grad.copy_(g)
+            self._rs_inflight.append((None, [], [(sp, None) for sp, _ in pend]))
             return
-        if self._avg_in_collective:  # RCCL: reduce-scatter with the average taken in the collective
-            w = dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-            self._works.append((w, (p, sp, None), False))
+        if self._avg_in_collective:  # RCCL: reduce-scatter with the average taken in the collective, one group call per bucket
+            works = None
+            try:
+                from torch.distributed.distributed_c10d import _coalescing_manager
+                with _coalescing_manager(group=self.group, device=pend[0][1].device, async_ops=True) as cm:
+                    for sp, g in pend:
+                        dist.reduce_scatter_tensor(sp._mi_shard_grad, g, op=dist.ReduceOp.AVG, group=self.group)
+                works = [cm]
+            except (ImportError, RuntimeError, TypeError, AttributeError):
+                works = [dist.reduce_scatter_tensor(sp._mi_shard_grad, g, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+                         for sp, g in pend]
+            self._rs_inflight.append((works, [g for _, g in pend], [(sp, None) for sp, _ in pend]))
             return
-        # gloo rehearsal (no reduce-scatter on this backend): all-reduce, scale, keep the rank's rows
-        w = dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._works.append((w, (p, sp, full), True))
+        # gloo rehearsal (no reduce-scatter on this backend): all-reduce, then keep the rank's rows x 1 / world
+        works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for _, g in pend]
+        self._rs_inflight.append((works, [], [(sp, g) for sp, g in pend]))
+
+    def _settle(self, entry):
+        works, _keep, items = entry
+        for w in (works or []):
+            w.wait()
+        for sp, full in items:
+            if full is not None:
+                _, r0, n = sp._mi_shard_of
+                sp._mi_shard_grad.copy_(full[r0:r0 + n]).mul_(1.0 / self.world)
+            sp.grad = sp._mi_shard_grad
 
     def _finalize(self):
-        # sharded buckets carry (master, shard, full-gradient-or-None) instead of a flat arena slice: settle them here, the
-        # base class then handles the all-reduced buckets and the row-sparse embedding part
-        rest = []
-        for w, flat, summed in self._works:
-            if isinstance(flat, tuple):
-                p, sp, full = flat
-                if w is not None:
-                    w.wait()
-                if full is not None:
-                    _, r0, n = sp._mi_shard_of
-                    sp._mi_shard_grad.copy_(full[r0:r0 + n]).mul_(1.0 / self.world)
-                sp.grad = sp._mi_shard_grad
-                p.grad = None  # the full-size gradient has served: the next pass starts from an empty slot
-            else:
-                rest.append((w, flat, summed))
-        self._works[:] = rest
-        super()._finalize()
+        try:
+            if self._sync:
+                # weights whose full gradient was accumulated under no_sync and got no new one in this pass cannot occur: the
+                # synchronising pass produces every gradient again; whatever is pending goes out now
+                for p in self._sharded.values():
+                    if p.grad is not None:  # accumulated under no_sync and completed by this pass
+                        g = p.grad
+                        p.grad = None
+                        self._rs_pending.append((self._shards[id(p)], g.contiguous()))
+                self._flush_reduce_scatters()
+                while self._rs_inflight:
+                    self._settle(self._rs_inflight.pop(0))
+        finally:
+            super()._finalize()
 
     # ------------------------------------------------------------------------------------------------ optimiser side
     def optimizer_param_groups(self):
         """Two groups for optim.ClippedAdamW: replicated parameters (every rank updates them identically) and the row shards
-        (`sharded=True`: their squared gradient norm is summed over the ranks before the clip coefficient is formed)."""
-        rep = [p for p in self.module.parameters() if p.requires_grad and id(p) not in self._sharded]
+        (`sharded=True`: their squared gradient norm is summed over the ranks of `dp_group` before the clip coefficient is formed)."""
         seen, rep_u = set(), []
-        for p in rep:
-            if id(p) not in seen:
+        for p in self.module.parameters():
+            if p.requires_grad and id(p) not in self._sharded and id(p) not in seen:
                 seen.add(id(p))
                 rep_u.append(p)
-        return [{"params": rep_u}, {"params": list(self._shards.values()), "sharded": True}]
+        return [{"params": rep_u}, {"params": list(self._shards.values()), "sharded": True, "dp_group": self.group}]
+
+    def _check_recipe(self, sink):
+        arena = getattr(sink, "arena", None)
+        rec = getattr(arena, "recipe", None)
+        if self.world > 1 and rec is not None and not getattr(rec, "reduce_amax", True):
+            raise RuntimeError("ShardedFP8DP needs reduce_amax=True: every rank quantises ITS rows of a weight, so the ranks must "
+                               "derive the same scale from the global amax")
+
+    def _sinks_in_forward_order(self):
+        """(module, [sinks]) in registration order ~ the order the next forward uses them."""
+        out = []
+        for m in self._fp8_modules:
+            ss = [v for k, v in m._wcache.items() if isinstance(k, tuple) and k[0] in ("sink", "mxsink")
+                  and all(id(w) in self._sharded for w, _, _ in v.parts)]
+            if ss:
+                out.append((m, ss))
+        return out
+
+    def _gather_ops(self, sink):
+        """The all-gathers of one operand as (dst, src) pairs plus the fix-ups to run once they have landed."""
+        ops_, fix = [], []
+        mx = hasattr(sink, "sc")
+        K = sink.w8.shape[1]
+        for w, row_off, n in sink.parts:
+            rows = n // self.world
+            lo = row_off + self.rank * rows
+            dst = sink.w8[row_off:row_off + n]
+            ops_.append((dst.view(-1), dst[self.rank * rows:(self.rank + 1) * rows].clone().view(-1)))
+            if mx:
+                d2 = sink.sct[row_off // 32:(row_off + n) // 32]
+                ops_.append((d2.view(-1), sink.sct[lo // 32:(lo + rows) // 32].clone().view(-1)))
+                # column blocks of [K/32, N] and [K, N]: gathered rank-major into scratch, then laid out
+                t_sc = torch.empty((self.world, sink.sc.shape[0], rows), dtype=torch.uint8, device=sink.sc.device)
+                t_wt = torch.empty((self.world, K, rows), dtype=torch.uint8, device=sink.wt8.device)
+                ops_.append((t_sc.view(-1), sink.sc[:, lo:lo + rows].contiguous().view(-1)))
+                ops_.append((t_wt.view(-1), sink.wt8[:, lo:lo + rows].contiguous().view(-1)))
+                fix.append((sink.sc[:, row_off:row_off + n], t_sc))
+                fix.append((sink.wt8[:, row_off:row_off + n], t_wt))
+        return ops_, fix
+
+    def _launch_gather(self, sinks, blocking: bool):
+        pairs, per_sink = [], []
+        for sink in sinks:
+            self._check_recipe(sink)
+            o, f = self._gather_ops(sink)
+            pairs += o
+            per_sink.append((sink, f))
+        works = []
+        if self.world > 1 or _FORCE_COLLECTIVES:
+            try:
+                if blocking or not self._avg_in_collective:
+                    raise TypeError
+                from torch.distributed.distributed_c10d import _coalescing_manager
+                with _coalescing_manager(group=self.group, device=pairs[0][0].device, async_ops=True) as cm:
+                    for dst, src in pairs:
+                        dist.all_gather_into_tensor(dst, src, group=self.group)
+                works = [cm]
+            except (ImportError, RuntimeError, TypeError, AttributeError):
+                works = [dist.all_gather_into_tensor(dst, src, group=self.group, async_op=True) for dst, src in pairs]
+        for sink, f in per_sink:
+            # the stamp the bytes in flight deserve: parameter versions and scale-arena generation AS OF THEIR QUANTISATION (now).
+            # Stamping at wait time would declare them current under a scale that has moved on since (per-layer autocasts
+            # without an outer one bump the generation between this launch and the forward that waits)
+            sink.mark()
+            stamp, sink.stamp = sink.stamp, None
+            self._gathers[id(sink)] = (works, f, stamp)
+        if blocking:
+            for sink, _ in per_sink:
+                self.wait_operand(sink)
+
+    def wait_operand(self, sink):
+        """Called by the module before it reads the sink: wait (stream-side) for the operand's all-gather, finish it locally."""
+        ent = self._gathers.pop(id(sink), None)
+        if ent is None:
+            return
+        from .pytorch import ops
+        works, fix, stamp = ent
+        for w in works:
+            w.wait()
+        for dst, tmp in fix:  # [world, R, rows] -> [R, world * rows]
+            dst.view(dst.shape[0], self.world, tmp.shape[2]).copy_(tmp.permute(1, 0, 2))
+        if hasattr(sink, "w8t"):
+            ops.transpose_u8(sink.w8, out=sink.w8t)
+        sink.stamp = stamp
 
     def after_optimizer_step(self):
-        """All-gather the freshly quantised FP8 rows of every sharded operand (1 byte per parameter), rebuild the transposed
-        copies locally, and declare the copies current."""
-        from .pytorch import ops
-        sinks = {}
-        for p in self._sharded.values():
-            s = getattr(p, "_mi_fp8_sink", None)
-            if s is not None:
-                sinks[id(s[0])] = s[0]
-            elif self.world > 1:
-                # no FP8 sink (MXFP8 recipe, FP8 off): the module will read the bf16 master itself -> gather its rows (2 B/param)
-                n = p.shape[0] // self.world
-                mine = p.data[self.rank * n:(self.rank + 1) * n].clone()
-                dist.all_gather_into_tensor(p.data.view(-1), mine.view(-1), group=self.group)
-        for sink in sinks.values():
-            if not all(id(w) in self._sharded for w, _, _ in sink.parts):
-                sink.stamp = None  # an operand with a replicated part was updated in full by every rank's optimiser already
-                continue
-            for w, row_off, n in sink.parts:
-                rows = n // self.world
-                dst = sink.w8[row_off:row_off + n]
-                if self.world > 1 or _FORCE_COLLECTIVES:
-                    mine = dst[self.rank * rows:(self.rank + 1) * rows].clone()
-                    dist.all_gather_into_tensor(dst.view(-1), mine.view(-1), group=self.group)
-            ops.transpose_u8(sink.w8, out=sink.w8t)
-            sink.mark()
+        """Issue the FP8 all-gathers of the freshly quantised shards: asynchronously, module by module in next-forward order."""
+        for _m, sinks in self._sinks_in_forward_order():
+            self._launch_gather(sinks, blocking=False)
 
+    def refresh_operand(self, sink, fmt: int):
+        """Delayed scaling, sink not current: cast this rank's rows with the CURRENT scale (amax deposited as the forward cast
+        would), gather, transpose.  Collective: every rank reaches it at the same point of its forward."""
+        from .pytorch import ops
+        for w, row_off, n in sink.parts:
+            h = w._mi_sharded
+            ops.cast_amax(h.shard.data, sink.scale, sink.amax, fmt, y=sink.w8[row_off + h.r0:row_off + h.r0 + h.rows], want_t=False)
+        self._launch_gather([sink], blocking=True)
+
+    def refresh_mx_operand(self, sink, fmt: int):
+        from .pytorch import ops
+        for w, row_off, n in sink.parts:
+            h = w._mi_sharded
+            lo = row_off + h.r0
+            ops.mxfp8_quantize(h.shard.data, fmt, rowwise=True, colwise=True,
+                               out=(sink.w8[lo:lo + h.rows], sink.sc[:, lo:lo + h.rows], sink.wt8[:, lo:lo + h.rows],
+                                    sink.sct[lo // 32:(lo + h.rows) // 32]))
+        self._launch_gather([sink], blocking=True)
+
+    # ------------------------------------------------------------------------------------------------ full masters on request
     def gather_master_weights(self):
-        """Refresh the full bf16 master tensors from the ranks' shards (evaluation with FP8 off, checkpoints)."""
-        if self.world == 1:
-            return
+        """Materialise the full bf16 master of every sharded weight on every rank (checkpoint, evaluation with FP8 off).
+        Collective.  `reshard()` releases them; training may continue either way (the shards stay the source of truth)."""
         with torch.no_grad():
             for p in self._sharded.values():
-                n = p.shape[0] // self.world
-                mine = p.data[self.rank * n:(self.rank + 1) * n].clone()
-                dist.all_gather_into_tensor(p.data.view(-1), mine.view(-1), group=self.group)
+                sp = self._shards[id(p)]
+                full = torch.empty(p._mi_full_shape, dtype=sp.dtype, device=sp.device)
+                if self.world > 1 or _FORCE_COLLECTIVES:
+                    dist.all_gather_into_tensor(full.view(-1), sp.data.contiguous().view(-1), group=self.group)
+                else:
+                    full.copy_(sp.data)
+                p.data = full
+        self._materialised = True
+
+    def reshard(self):
+        with torch.no_grad():
+            for p in self._sharded.values():
+                p.data = torch.zeros(1, dtype=p.dtype, device=p.device).expand(p._mi_full_shape)
+        self._materialised = False
 
     def describe(self) -> dict:
         d = super().describe()
+        nb = lambda t: t.numel() * t.element_size()
+        shards = list(self._shards.values())
         d["sharded_weights"] = len(self._sharded)
-        d["sharded_bytes"] = sum(p.numel() * p.element_size() for p in self._sharded.values())
+        d["sharded_logical_bytes"] = sum(int(torch.tensor(p._mi_full_shape).prod()) * 2 for p in self._sharded.values())
+        d["master_bytes"] = sum(nb(sp.data) for sp in shards) + (d["sharded_logical_bytes"] if self._materialised else 0)
+        d["shard_grad_bytes"] = sum(nb(sp._mi_shard_grad) for sp in shards)
+        d["module_param_storage_bytes"] = sum(p.untyped_storage().nbytes() for p in self._sharded.values())
+        fp8 = 0
+        for _m, sinks in self._sinks_in_forward_order():
+            for s_ in sinks:
+                fp8 += sum(nb(getattr(s_, a)) for a in ("w8", "w8t", "wt8", "sc", "sct") if hasattr(s_, a))
+        d["fp8_operand_bytes"] = fp8
         return d
 
 

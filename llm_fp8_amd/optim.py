@@ -46,7 +46,7 @@ class ClippedAdamW(torch.optim.Optimizer):
             full, sr0, sn = sh
             fs = getattr(full, "_mi_fp8_sink", None)
             s = None if fs is None else (fs[0], fs[1] + sr0, sn)
-        if s is None or not p.is_contiguous() or p.dim() != 2:
+        if s is None or not p.is_contiguous() or p.dim() != 2 or not ClippedAdamW._aligned16(p):
             return None
         sink, r0, n = s
         if n != p.shape[0] or sink.w8.shape[1] != p.shape[1] or p.shape[0] % 8 or p.shape[1] % 8:
@@ -54,12 +54,26 @@ class ClippedAdamW(torch.optim.Optimizer):
         return s
 
     @staticmethod
+    def _aligned16(p) -> bool:
+        """The tile path of the *_cast kernels issues 16-byte loads / stores on the parameter, its gradient and both moments
+        unconditionally; a tensor at an odd storage offset (a loaded optimiser state, a `.grad` view) takes the flat path."""
+        if p.data_ptr() % 16:
+            return False
+        g = p.grad
+        return g is None or g.data_ptr() % 16 == 0
+
+    @staticmethod
     def _mx_sink_of(p):
         """(sink, row offset, rows) when the MXFP8 copies of this weight are kept current by the optimiser (module.MXWeightSink)."""
         if os.environ.get("LLM_FP8_AMD_NO_OPT_WCAST") == "1":
             return None
         s = getattr(p, "_mi_mx_sink", None)
-        if s is None or not p.is_contiguous() or p.dim() != 2:
+        sh = getattr(p, "_mi_shard_of", None)
+        if sh is not None:  # a row shard of a master weight (distributed.ShardedFP8DP)
+            full, sr0, sn = sh
+            fs = getattr(full, "_mi_mx_sink", None)
+            s = None if fs is None else (fs[0], fs[1] + sr0, sn)
+        if s is None or not p.is_contiguous() or p.dim() != 2 or not ClippedAdamW._aligned16(p):
             return None
         sink, r0, n = s
         if n != p.shape[0] or sink.w8.shape[1] != p.shape[1] or p.shape[0] % 32 or p.shape[1] % 32 or r0 % 32:
@@ -196,8 +210,9 @@ class ClippedAdamW(torch.optim.Optimizer):
                     total = t if total is None else total + t
             if shard_total is not None:
                 import torch.distributed as dist
-                if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                    dist.all_reduce(shard_total, op=dist.ReduceOp.SUM)
+                grp = next((gi[0][0].get("dp_group") for gi, _ in plans if gi[0][0].get("sharded", False)), None)
+                if dist.is_available() and dist.is_initialized() and dist.get_world_size(grp) > 1:
+                    dist.all_reduce(shard_total, op=dist.ReduceOp.SUM, group=grp)
                 total = shard_total if total is None else total + shard_total
             total = total.sqrt()
             self.last_grad_norm = total

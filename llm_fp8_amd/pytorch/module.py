@@ -141,6 +141,35 @@ def weight_sinks_enabled() -> bool:
     return os.environ.get("LLM_FP8_AMD_NO_OPT_WCAST") != "1"
 
 
+def sharded_handle(weights):
+    """distributed.ShardedFP8DP marks a weight whose bf16 master rows live 1/world per rank with `_mi_sharded` (the Parameter the
+    module holds keeps its logical shape but no storage).  Such an operand has ONE source of FP8 bytes: its sink, filled by the
+    optimiser's rows + an FP8 all-gather -- or, whenever the sink is not current (first step, scale arena moved on, checkpoint
+    load, evaluation first), by `handle.dp.refresh_*`: quantise the local rows now and gather.  Returns the handle or None; a
+    mix of sharded and replicated parts in one operand is refused."""
+    hs = [getattr(w, "_mi_sharded", None) for w in weights]
+    if all(h is None for h in hs):
+        return None
+    if any(h is None for h in hs):
+        raise RuntimeError("an FP8 GEMM operand mixes row-sharded and replicated weight parts (distributed.ShardedFP8DP shards all "
+                           "parts of an operand or none)")
+    return hs[0]
+
+
+def _master(w):
+    """The bf16 master of a weight for the unquantised path (FP8 disabled): a row-sharded weight has none on this rank."""
+    if getattr(w, "_mi_sharded", None) is not None and not w.is_contiguous():
+        raise RuntimeError("this weight is row-sharded (distributed.ShardedFP8DP): its bf16 master exists 1/world per rank, so the "
+                           "unquantised path cannot run -- keep FP8 enabled, or materialise the masters first with "
+                           "dp.gather_master_weights() (and dp.reshard() afterwards)")
+    return w
+
+
+def _weight_ok_for_sink(w, K: int) -> bool:
+    return (isinstance(w, torch.nn.Parameter) and w.dtype == torch.bfloat16 and w.dim() == 2 and w.shape[1] == K
+            and (w.is_contiguous() or getattr(w, "_mi_sharded", None) is not None))
+
+
 class MXWeightSink:
     """MXFP8 copies (row-wise w8 [N,K] + E8M0 [K/32,N]; column-wise, stored transposed, wt8 [K,N] + E8M0 [N/32,K]) of one GEMM's
     weight operand that the OPTIMISER keeps current (optim.ClippedAdamW -> mi_adamw_mxcast_bf16_multi).  Block scaling has no
@@ -168,20 +197,28 @@ class MXWeightSink:
 
 def _mx_sink_copies(spec: _GemmSpec, g: int, weights, ns, N: int, K: int, dev):
     """(w8, sc, wt8, sct) from the optimiser-maintained sink of GEMM `g` if they are current, else None (the caller quantises).
-    A training pass creates the sink the first time round; the optimiser fills it at its next step."""
-    if spec.wcache is None or spec.fmt_fwd != 0 or not weight_sinks_enabled():
+    A training pass creates the sink the first time round; the optimiser fills it at its next step.  Row-sharded weights
+    (distributed.ShardedFP8DP) always go through the sink: a stale one is refreshed from the ranks' shards."""
+    shard = sharded_handle(weights)
+    if shard is None and (spec.wcache is None or spec.fmt_fwd != 0 or not weight_sinks_enabled()):
         return None
+    if shard is not None and (spec.wcache is None or spec.fmt_fwd != 0):
+        raise RuntimeError("row-sharded weights need the module's FP8 weight cache and an E4M3 forward format")
     sink = spec.wcache.get(("mxsink", g))
     stale = sink is None or len(sink.parts) != len(weights) or any(a is not b for (a, _, _), b in zip(sink.parts, weights))
     if stale:
-        if not spec.training:
+        if not spec.training and shard is None:
             return None
-        ok = (N % 32 == 0 and K % 32 == 0 and all(n % 32 == 0 for n in ns) and
-              all(isinstance(w, torch.nn.Parameter) and w.dtype == torch.bfloat16 and w.is_contiguous() and w.dim() == 2 and w.shape[1] == K
-                  for w in weights))
+        ok = (N % 32 == 0 and K % 32 == 0 and all(n % 32 == 0 for n in ns) and all(_weight_ok_for_sink(w, K) for w in weights))
         if not ok:
+            if shard is not None:
+                raise RuntimeError("row-sharded weights of this shape cannot take an MXFP8 sink")
             return None
         sink = spec.wcache[("mxsink", g)] = MXWeightSink(weights, ns, N, K, dev)
+    if shard is not None:
+        shard.dp.wait_operand(sink)            # an FP8 all-gather issued after the optimiser step may still be in flight
+        if not sink.fresh():
+            shard.dp.refresh_mx_operand(sink, spec.fmt_fwd)
     return (sink.w8, sink.sc, sink.wt8, sink.sct) if sink.fresh() else None
 
 
@@ -196,17 +233,27 @@ def _cast_weights(spec: _GemmSpec, g: int, weights, ns, N: int, K: int, dev, nee
             return hit
     # (no grad-mode test here: inside an autograd Function's forward grad mode is always off; fresh copies are the bytes a
     # cast would produce now in any mode)
-    if spec.wcache is not None and spec.fmt_fwd == 0 and weight_sinks_enabled():
+    shard = sharded_handle(weights)
+    if shard is not None and (spec.wcache is None or spec.fmt_fwd != 0):
+        raise RuntimeError("row-sharded weights need the module's FP8 weight cache and an E4M3 forward format")
+    if spec.wcache is not None and spec.fmt_fwd == 0 and (weight_sinks_enabled() or shard is not None):
         sink = spec.wcache.get(("sink", g))
         stale = sink is None or sink.arena is not mf.arena or len(sink.parts) != len(weights) or any(a is not b for (a, _, _), b in zip(sink.parts, weights))
-        if stale and not spec.training:
+        if stale and not spec.training and shard is None:
             sink = None  # sinks are created by training passes only; an evaluation pass may USE a fresh one (same bytes)
         elif stale:
-            if all(w.dtype == torch.bfloat16 and w.is_contiguous() and w.dim() == 2 and w.shape[1] == K and isinstance(w, torch.nn.Parameter)
-                   for w in weights) and N % 8 == 0 and K % 8 == 0:
+            if all(_weight_ok_for_sink(w, K) for w in weights) and N % 8 == 0 and K % 8 == 0:
                 sink = spec.wcache[("sink", g)] = WeightSink(weights, ns, N, K, dev, mf, 3 * g + 1)
             else:
                 sink = None
+        if shard is not None:
+            if sink is None:
+                raise RuntimeError("row-sharded weights of this shape cannot take an FP8 sink")
+            shard.dp.wait_operand(sink)        # an FP8 all-gather issued after the optimiser step may still be in flight
+            if not sink.fresh():
+                # the bytes in the sink were quantised with another scale generation (or never): the only bf16 source is the
+                # ranks' shards -- cast the local rows with the CURRENT scale and gather (what a replicated run's forward cast does)
+                shard.dp.refresh_operand(sink, spec.fmt_fwd)
         if sink is not None and sink.fresh():
             siw = mf.scale_inv_snapshot()[3 * g + 1:3 * g + 2]
             if spec.first_mb is True:
@@ -276,6 +323,9 @@ def _wgrad_out(weights, K: int) -> Optional[torch.Tensor]:
     """Destination of the weight-gradient GEMM inside the data-parallel gradient arena (distributed.GradArenaDP): the
     [sum N_i, K] block formed by the weights' slots when these are adjacent and in order, the parameters are bf16 and
     nothing has been accumulated into them yet (gradient accumulation adds into `.grad` instead).  None otherwise."""
+    shard = getattr(weights[0], "_mi_sharded", None)
+    if shard is not None:  # distributed.ShardedFP8DP: a transient [sum N_i, K] buffer that lives until its reduce-scatter has run
+        return shard.dp.wgrad_buffer(weights, K)
     slot = getattr(weights[0], "_mi_grad_slot", None)
     if slot is None:
         return None
@@ -743,7 +793,7 @@ class Linear(_FP8Module):
             is_first_microbatch = self.default_is_first_microbatch
         st = self._prepare(inp.device)
         if st is None:
-            return F.linear(inp, self.weight.to(inp.dtype), None if self.bias is None else self.bias.to(inp.dtype))
+            return F.linear(inp, _master(self.weight).to(inp.dtype), None if self.bias is None else self.bias.to(inp.dtype))
         recipe, mf, mb, first = st
         # `offer_dy_handoff` (set on the lm_head by train.prepare_model): the output carries a DyHandoff through which the op
         # that consumes it directly (loss.causal_lm_loss) can deliver this layer's grad_output already quantised
@@ -831,7 +881,7 @@ class LayerNormLinear(_FP8Module):
                                       self.layer_norm_weight, *ws)
         ln = self._norm(inp)
         if st is None:
-            w = ws[0] if len(ws) == 1 else torch.cat(ws, 0)
+            w = _master(ws[0]) if len(ws) == 1 else torch.cat([_master(w_) for w_ in ws], 0)
             out = F.linear(ln, w.to(ln.dtype), None if b is None else b.to(ln.dtype))
         else:
             recipe, mf, mb, first = st
@@ -919,8 +969,8 @@ class LayerNormMLP(_FP8Module):
     def _unfused(self, inp, st, is_first_microbatch):
         ln = self._norm(inp)
         if st is None:
-            h = F.linear(ln, self.fc1_weight.to(ln.dtype), None if self.fc1_bias is None else self.fc1_bias.to(ln.dtype))
-            return F.linear(self.act_fn(h), self.fc2_weight.to(ln.dtype),
+            h = F.linear(ln, _master(self.fc1_weight).to(ln.dtype), None if self.fc1_bias is None else self.fc1_bias.to(ln.dtype))
+            return F.linear(self.act_fn(h), _master(self.fc2_weight).to(ln.dtype),
                             None if self.fc2_bias is None else self.fc2_bias.to(ln.dtype))
         recipe, mf, mb, first = st
         if self.activation == "swiglu" and self.fused_swiglu and (recipe.delayed() or inp.numel() // inp.shape[-1] % 32 == 0):

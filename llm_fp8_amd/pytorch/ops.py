@@ -45,7 +45,11 @@ def default_gemm_algo() -> int:
     d = torch.distributed
     if d.is_available() and d.is_initialized() and d.get_world_size() > 1:
         return 5
-    return 47 if os.environ.get("LLM_FP8_AMD_GEMM_W4", "1") != "0" else 0
+    # LLM_FP8_AMD_GEMM_W4=1: auto with the persistent four-wave kernel (mi_gemm_w4.hip) on the shapes it takes.  Off by default: it is
+    # 2-5 % faster per launch on the no-bias 256-multiple shapes but those are ~13 % of the step's GEMM time (the biased fc1 / fc2
+    # forward and the grouped backward launches stay on the eight-wave kernel), and the same-box A/B of the whole step reads the
+    # same tokens/s either way (profiles/r03_instep_w4_ab.txt)
+    return 47 if os.environ.get("LLM_FP8_AMD_GEMM_W4", "0") == "1" else 0
 
 
 def _stream() -> int:

@@ -121,7 +121,7 @@ def resolve_sharding_mode(mode: str, model: torch.nn.Module, device) -> str:
     """`auto` (DistributedConfig._auto_detect_sharding, train_multi_gpu.py:137-146, picks FSDP FULL_SHARD whenever there is
     more than one GPU): here the run shards only when it has to -- the replicated state of every BASELINE.json model fits
     one MI355X (3B: 39 GB, 8B: 96 GB of 288 GB), so `auto` = gradient-arena data parallelism (distributed.GradArenaDP),
-    and FSDP FULL_SHARD only for a model whose replicated state would take more than half of the device.  An explicit
+    and the full-shard mode (`fsdp_fp8`) only for a model whose replicated state would take more than half of the device.  An explicit
     ddp / fsdp_full / replicated request is honoured even at world size 1 (rehearsal on a one-GPU box)."""
     import torch.distributed as dist
     if mode != "auto":
@@ -129,7 +129,9 @@ def resolve_sharding_mode(mode: str, model: torch.nn.Module, device) -> str:
     if dist.get_world_size() == 1:
         return "none"
     from .distributed import fits_replicated
-    return "replicated" if fits_replicated(model, device) else "fsdp_full"
+    # does not fit: the FULL_SHARD counterpart with FP8 all-gathers (distributed.ShardedFP8DP; masters, gradients and AdamW
+    # moments of every GEMM weight at 1/world per rank), not torch FSDP (bf16 gathers in forward and backward, a cast after each)
+    return "replicated" if fits_replicated(model, device) else "fsdp_fp8"
 
 
 def _single_process(model: torch.nn.Module, device) -> torch.nn.Module:
@@ -330,6 +332,8 @@ def main(argv=None):
         if rank == 0:
             files = save_model(model, cfg, a.save_layout)
             print(json.dumps({"saved": files}), flush=True)
+        if hasattr(model, "reshard"):
+            model.reshard()
 
 
 if __name__ == "__main__":

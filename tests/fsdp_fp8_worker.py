@@ -14,9 +14,9 @@ from llm_fp8_amd import train  # noqa: E402
 from llm_fp8_amd.pytorch.fp8 import FP8GlobalStateManager as G  # noqa: E402
 
 
-def run(mode, scenario, rank, device, steps=4):
+def run(mode, scenario, rank, device, steps=4, mixed_precision="fp8"):
     G.reset()
-    cfg = train.TrainingConfig(model_name="llama-3.2-1b", batch_size=4, max_seq_length=128, mixed_precision="fp8",
+    cfg = train.TrainingConfig(model_name="llama-3.2-1b", batch_size=4, max_seq_length=128, mixed_precision=mixed_precision,
                                fp8_scenario=scenario, use_te=True, sharding_mode=mode, num_hidden_layers=2,
                                vocab_size=4096, learning_rate=1e-3, num_warmup_steps=0)
     torch.manual_seed(4321)
@@ -31,10 +31,18 @@ def run(mode, scenario, rank, device, steps=4):
     with torch.no_grad():
         ev = dp(**train.synthetic_batch(cfg, 4096, device, torch.Generator(device=device).manual_seed(5))).loss.item()
     dp.train()
+    info = dp.describe()   # BEFORE the masters are materialised: the resident training state
+    if mode == "fsdp_fp8":
+        shard_ids = {id(sp) for sp in dp._shards.values()}
+        info["shard_moment_bytes"] = sum(st[k].numel() * st[k].element_size() for p_, st in opt.state.items() if id(p_) in shard_ids
+                                         for k in ("exp_avg", "exp_avg_sq"))
+        info["full_grads_alive"] = sum(1 for p_ in dp._sharded.values() if p_.grad is not None)
     if hasattr(dp, "gather_master_weights"):
         dp.gather_master_weights()
     flat = torch.cat([p.detach().reshape(-1).view(torch.int16) for p in model.parameters()]).clone()
-    info = dp.describe()
+    if hasattr(dp, "reshard"):
+        dp.reshard()
+        assert all(p_.untyped_storage().nbytes() <= 8 for p_ in dp._sharded.values())
     moments = sum(st["exp_avg"].numel() for st in opt.state.values())
     del dp, opt, model
     torch.cuda.empty_cache()
@@ -43,12 +51,17 @@ def run(mode, scenario, rank, device, steps=4):
 
 def main():
     scenario = sys.argv[1]
+    mp = "fp8"
+    if scenario.endswith("-bf16"):  # --mixed_precision bf16 --use_te: no outer autocast, every layer's own autocast updates the arena
+        scenario, mp = scenario[:-5], "bf16"
     rank, local, world, device = train.setup_distributed()
-    l_rep, e_rep, w_rep, _, _, mom_rep = run("replicated", scenario, rank, device)
-    l_sh, e_sh, w_sh, _, info, mom_sh = run("fsdp_fp8", scenario, rank, device)
+    l_rep, e_rep, w_rep, _, _, mom_rep = run("replicated", scenario, rank, device, mixed_precision=mp)
+    l_sh, e_sh, w_sh, _, info, mom_sh = run("fsdp_fp8", scenario, rank, device, mixed_precision=mp)
     print(json.dumps({"rank": rank, "world": world, "losses_equal": l_rep == l_sh, "eval_equal": e_rep == e_sh,
                       "weights_equal": bool(torch.equal(w_rep, w_sh)), "losses": l_sh, "losses_rep": l_rep, "eval": [e_rep, e_sh],
-                      "sharded_weights": info.get("sharded_weights", 0), "moment_elems": [mom_rep, mom_sh]}), flush=True)
+                      "sharded_weights": info.get("sharded_weights", 0), "moment_elems": [mom_rep, mom_sh],
+                      "mem": {k: info.get(k) for k in ("sharded_logical_bytes", "master_bytes", "shard_grad_bytes", "shard_moment_bytes",
+                                                       "module_param_storage_bytes", "fp8_operand_bytes", "full_grads_alive")}}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

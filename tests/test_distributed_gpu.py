@@ -56,12 +56,16 @@ def test_fsdp_full_shard_matches_the_unwrapped_run(dev, world, scenario):
             assert o["worst_rel"] <= 2.0 ** -7, o                  # bf16 sum of two bf16 gradients, then x 1/2
 
 
-@pytest.mark.parametrize("world,scenario", [(2, "default"), (2, "hybrid"), (2, "mxfp8"), (1, "default")])
+@pytest.mark.parametrize("world,scenario", [(2, "default"), (2, "hybrid"), (2, "mxfp8"), (1, "default"), (1, "mxfp8"), (2, "default-bf16")])
 def test_sharded_fp8_dp_matches_the_replicated_run(dev, world, scenario):
-    """SURVEY.md 8f rank 3 (second half): distributed.ShardedFP8DP -- row-sharded AdamW + weight cast, reduce-scattered wgrads, ONE
-    FP8 all-gather per operand and step, no gather in backward -- must train exactly like the replicated wrapper: identical losses
-    at every step, identical evaluation loss, identical master weights after gather_master_weights(); and its AdamW moments take
-    1/world of the sharded weights' space.  2 ranks share the box's GPU (gloo transport); world 1 runs the RCCL collectives."""
+    """SURVEY.md 8f rank 3 (second half): distributed.ShardedFP8DP, the FULL_SHARD counterpart (train_multi_gpu.py:392-406, :414-445)
+    -- bf16 master rows, gradients and AdamW moments of every GEMM weight at 1/world per rank, reduce-scattered wgrads out of
+    transient buffers, asynchronous FP8 (+ E8M0 for MXFP8) all-gathers per operand, no gather in backward -- must train exactly
+    like the replicated wrapper: identical losses at every step, identical evaluation loss, identical master weights after
+    gather_master_weights(); and the RESIDENT state of the sharded weights is 1/world: masters, shard gradients and moments are
+    measured from the tensors that exist after training.  `default-bf16` = `--mixed_precision bf16 --use_te` (no outer
+    autocast: every layer's own autocast bumps the scale arena, so every sink is stale at every forward and is refreshed from
+    the shards -- the stale-master hole of round 2).  2 ranks share the box's GPU (gloo transport); world 1 runs RCCL."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     if world == 1:
         env.update(LLM_FP8_AMD_FORCE_DIST="1", LLM_FP8_AMD_FORCE_COLLECTIVES="1")
@@ -77,6 +81,12 @@ def test_sharded_fp8_dp_matches_the_replicated_run(dev, world, scenario):
         assert o["sharded_weights"] >= 12, o                 # 2 layers x (q, k, v, proj, fc1, fc2)
         assert o["losses_equal"] and o["eval_equal"] and o["weights_equal"], o
         assert all(l == l for l in o["losses"]), o
+        m = o["mem"]
+        assert m["master_bytes"] * world == m["sharded_logical_bytes"], m       # bf16 master rows: exactly 1 / world
+        assert m["shard_grad_bytes"] * world == m["sharded_logical_bytes"], m   # persistent gradients: 1 / world
+        assert m["shard_moment_bytes"] * world == 2 * m["sharded_logical_bytes"], m  # two bf16 moments per owned element
+        assert m["module_param_storage_bytes"] <= 8 * o["sharded_weights"], m   # the modules' Parameters hold no master storage
+        assert m["full_grads_alive"] == 0, m                                    # no full-size gradient survives the step
         if world == 2:
             assert o["moment_elems"][1] < 0.75 * o["moment_elems"][0], o   # the decoder's moments are halved (the tied table is not sharded)
     if world == 2:

@@ -3,7 +3,7 @@ import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from llm_fp8_amd import _lib
-lib = _lib.load()
+lib = _lib.use_lab_library()  # mi_attn_fwd_diag lives in the lab build (make -C llm_fp8_amd/csrc lab)
 P, I, I64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
 lib.mi_attn_fwd_diag.argtypes = [P, P, P, P, P, P, I, I, I, I, I, I64, I64, I64, I64, ctypes.c_float, P]
 dev = torch.device("cuda:0")

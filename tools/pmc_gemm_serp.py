@@ -4,6 +4,8 @@ Each shape: 3 launches of algo 4, then 3 of algo 30 (the last of each triple is 
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from llm_fp8_amd import _lib as _mi_lib
+_mi_lib.use_lab_library()  # algo 30 is a lab build
 from llm_fp8_amd.pytorch import ops
 from tools.bench_kernels import rand_fp8
 
