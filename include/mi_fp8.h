@@ -144,7 +144,7 @@ int mi_gemm_fp8_clock(const void* A, const void* B, void* D, const float* sa_inv
  * bias, in ONE persistent launch whose workgroups walk a shared tile list (longest tiles first) -- a Linear's dgrad + wgrad
  * (both consume the same grad_output) pay one ramp and one exposed epilogue, and the short problem's tiles fill
  * the idle part of the long one's last round of tiles.  All problems share fmt_a / fmt_b and the tile shape: tile_cfg
- * 0 = 256x256, 1 = 256x192, 2 = 192x256, 3 = 192x192, -1 = choose (M_p, N_p must be multiples of the tile, K_p of 256;
+ * 0 = 256x256, 1 = 256x192, 2 = 192x256, 3 = 192x192, 4 = 256x256 on the four-wave kernel (every K_p >= 512), -1 = choose among 0-3 (M_p, N_p must be multiples of the tile, K_p of 256;
  * operands below 2 GiB; at most 64 tiles per workgroup).  Results are bitwise those of mi_gemm_fp8(algo 4) per problem.
  */
 typedef struct mi_gemm_problem {

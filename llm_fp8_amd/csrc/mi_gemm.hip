@@ -1465,12 +1465,13 @@ static int launch_fmt(const void* A, const void* B, void* D, const float* sa_inv
     // four-wave kernel (mi_gemm_w4.hip): one tile per workgroup 6 = product, 7 = no stores, 8 = clock stamps; persistent
     // 9 = product, 10 = no stores, 11 = clock stamps, 12 = no epilogue (7, 8, 10-12: lab library only)
     const int variant = algo <= 8 ? algo - 6 : algo + 1;
-    if (bp != nullptr && algo != 8 && algo != 11) {
-      set_error("mi_gemm: the four-wave kernels (algo %d) take no bias", algo);
+    if (bp != nullptr && algo != 8 && algo != 9 && algo != 11) {
+      set_error("mi_gemm: of the four-wave kernels only the persistent one (algo 9) takes a bias (got algo %d)", algo);
       return MI_ERR_ARG;
     }
     if (clock_stamps != nullptr) return launch_w4(A, B, D, sa_inv, sb_inv, M, N, K, lda, ldb, ldd, FA, FB, 12, clock_stamps, st);
-    return launch_w4(A, B, D, sa_inv, sb_inv, M, N, K, lda, ldb, ldd, FA, FB, variant, (algo == 8 || algo == 11) ? (void*)bias : nullptr, st);
+    return launch_w4(A, B, D, sa_inv, sb_inv, M, N, K, lda, ldb, ldd, FA, FB, variant, (algo == 8 || algo == 11) ? (void*)bias : nullptr, st,
+                     algo == 9 ? (const void*)bp : nullptr);
 #ifdef MI_DIAG
   } else if (algo >= 70 && algo <= 73 && !mx) {  // persistent four-wave kernel, epilogue store policy: 70 plain, 71 nt, 72 sc1 + nt; 73: per-K-tile stamps
     return launch_w4(A, B, D, sa_inv, sb_inv, M, N, K, lda, ldb, ldd, FA, FB, algo - 56, algo == 73 ? (void*)bias : nullptr, st);
@@ -1555,9 +1556,9 @@ static int pick_algo(int algo, int64_t M, int64_t N, int64_t K, int64_t lda, int
     return algo;
   }
   if (algo == 47) {
-    // auto, four-wave kernel where it is the faster one (measured, profiles/r03_w4p_*): no bias, 256-multiples, K >= 512, and the
+    // auto, four-wave kernel where it is the faster one (measured, profiles/r03_w4p_*): 256-multiples, K >= 512, and the
     // eight-wave kernel's own tile-shape choice is 256 x 256 (where it prefers 192-wide tiles the round count decides)
-    if (p8_ok && !has_bias && M % 256 == 0 && N % 256 == 0 && K >= 512 && pick_tile_cfg(M, N, K) == 0 &&
+    if (p8_ok && M % 256 == 0 && N % 256 == 0 && K >= 512 && pick_tile_cfg(M, N, K) == 0 &&
         ((M / 256) * (N / 256) + num_cus() - 1) / num_cus() <= 64)
       return 9;
     algo = 0;

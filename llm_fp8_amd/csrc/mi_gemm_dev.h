@@ -107,9 +107,41 @@ __device__ __forceinline__ void wait_vmcnt() {
   __builtin_amdgcn_s_barrier();   \
   __builtin_amdgcn_sched_barrier(0);
 
+// ------------------------------------------------------------------------------------------------
+// Grouped launches (mi_gemm_grouped.hip: eight-wave kernel; mi_gemm_w4.hip: four-wave kernel, 256 x 256 tiles)
+constexpr int kMaxGroup = 4;
+
+struct GroupProblem {
+  const uint8_t* A;
+  const uint8_t* B;
+  uint16_t* D;
+  const float* sa_inv;
+  const float* sb_inv;
+  int lda, ldb, ldd, nk;
+  int tiles_m, tiles_n, tile_base, ntiles;
+  int a_bytes, b_bytes, d_bytes, pad;
+};
+
+constexpr int kMaxWg = 256;      // workgroups of the persistent grid (one per CU)
+constexpr int kMaxPerWg = 64;    // tiles per workgroup (one lane of the tile table each)
+
+// The schedule (host, longest-processing-time greedy, cached per shape): cnt[p][v] = tiles of problem p that the workgroup with
+// VIRTUAL index v walks (v = XCD-major order of the workgroups: neighbours in v share an L2).  Tile ids of a problem are bound
+// round-major: the j-th tile of workgroup v is id R[p][j] + #{v' < v : cnt[p][v'] > j}, so the workgroups of one XCD hold
+// consecutive ids -- adjacent tiles of the grouped order, sharing A/B panels -- at the same time.
+struct GroupArgs {
+  GroupProblem p[kMaxGroup];
+  int n, total_tiles;
+  uint8_t cnt[kMaxGroup][kMaxWg];
+  uint16_t R[kMaxGroup][kMaxPerWg];
+};
+
+// the grouped launch of the four-wave kernel (tile shape 256 x 256, every problem K >= 512)
+int launch_w4_grouped(const GroupArgs& ga, int fa, int fb, int grid, hipStream_t st);
+
 // mi_gemm_w4.hip: the four-wave (128x128 wave tile) kernel.  variant 0 = product, 1 = no stores, 2 = clock stamps (dbg)
 int launch_w4(const void* A, const void* B, void* D, const float* sa_inv, const float* sb_inv, int64_t M, int64_t N, int64_t K,
-              int64_t lda, int64_t ldb, int64_t ldd, int fa, int fb, int variant, void* dbg, hipStream_t st);
+              int64_t lda, int64_t ldb, int64_t ldd, int fa, int fb, int variant, void* dbg, hipStream_t st, const void* bias = nullptr);
 
 static inline int num_cus() {
   static int n = 0;  // benign race: every thread computes the same value

@@ -22,19 +22,6 @@
 
 namespace mi {
 
-constexpr int kMaxGroup = 4;
-
-struct GroupProblem {
-  const uint8_t* A;
-  const uint8_t* B;
-  uint16_t* D;
-  const float* sa_inv;
-  const float* sb_inv;
-  int lda, ldb, ldd, nk;
-  int tiles_m, tiles_n, tile_base, ntiles;
-  int a_bytes, b_bytes, d_bytes, pad;
-};
-
 // prefetch cursor: the (tile, K-tile) of a future step with everything needed to stage from it (wave-uniform)
 struct Cursor {
   int ti, kt, nk, oa, ob, lda, ldb;
@@ -47,20 +34,6 @@ struct Epi {
   rsrc_t rsD;
   int ldd, d_off;
   float alpha;
-};
-
-constexpr int kMaxWg = 256;      // workgroups of the persistent grid (one per CU)
-constexpr int kMaxPerWg = 64;    // tiles per workgroup (one lane of the tile table each)
-
-// The schedule (host, longest-processing-time greedy, cached per shape): cnt[p][v] = tiles of problem p that the workgroup with
-// VIRTUAL index v walks (v = XCD-major order of the workgroups: neighbours in v share an L2).  Tile ids of a problem are bound
-// round-major: the j-th tile of workgroup v is id R[p][j] + #{v' < v : cnt[p][v'] > j}, so the workgroups of one XCD hold
-// consecutive ids -- adjacent tiles of the grouped order, sharing A/B panels -- at the same time.
-struct GroupArgs {
-  GroupProblem p[kMaxGroup];
-  int n, total_tiles;
-  uint8_t cnt[kMaxGroup][kMaxWg];
-  uint16_t R[kMaxGroup][kMaxPerWg];
 };
 
 template <int FA, int FB, int MA1, int NB1>
@@ -530,7 +503,9 @@ extern "C" int mi_gemm_fp8_grouped(const mi_gemm_problem* problems, int n, int f
   static const int bm[4] = {256, 256, 192, 192}, bn[4] = {256, 192, 256, 192};
   const int ncu = num_cus();
   // tile shape: the caller's, or the one that minimises rounds x tile area / efficiency over the WHOLE group (mi_gemm.hip pick_tile_cfg)
-  int cfg = tile_cfg;
+  // tile_cfg 4 = 256 x 256 tiles on the four-wave kernel (mi_gemm_w4.hip; every problem K >= 512): same schedule, other kernel
+  const bool four_wave = tile_cfg == 4;
+  int cfg = four_wave ? 0 : tile_cfg;
   if (cfg < 0) {
     static const double eff[4] = {1.0, 0.90, 0.90, 0.80};
     double best = 0;
@@ -607,6 +582,7 @@ extern "C" int mi_gemm_fp8_grouped(const mi_gemm_problem* problems, int n, int f
   std::memcpy(ga.cnt, sc.cnt, sizeof(ga.cnt));
   std::memcpy(ga.R, sc.R, sizeof(ga.R));
   hipStream_t st = (hipStream_t)stream;
+  if (four_wave) return launch_w4_grouped(ga, fmt_a, fmt_b, grid, st);
   if (fmt_a == 0 && fmt_b == 0) return launch_grouped<0, 0>(ga, cfg, grid, st);
   if (fmt_a == 1 && fmt_b == 0) return launch_grouped<1, 0>(ga, cfg, grid, st);
   if (fmt_a == 0 && fmt_b == 1) return launch_grouped<0, 1>(ga, cfg, grid, st);

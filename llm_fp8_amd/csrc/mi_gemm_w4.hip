@@ -351,88 +351,163 @@ __device__ __forceinline__ void mfma_acc_zero(const v8i& a, const v8i& b, v4f& a
                : "v"(b), "v"(a), "v"(unit), "n"(FB), "n"(FA));
 }
 
+// Kernel arguments of the one-problem forms
+struct W4Single {
+  const uint8_t* A;
+  const uint8_t* B;
+  uint16_t* D;
+  const float* sa_inv;
+  const float* sb_inv;
+  const uint16_t* bias;  // MODE 1: bf16 [n_cols]
+  unsigned long long* dbg;
+  int K, lda, ldb, ldd, tiles_m, tiles_n, a_bytes, b_bytes, d_bytes, n_cols;
+};
+
+// MODE: 0 = one problem; 1 = one problem + bias (bf16 [N], added after the alpha multiply as the eight-wave kernel does: two
+// roundings); 2 = grouped: up to 4 problems in one launch, tiles dealt by the host's longest-processing-time schedule
+// (GroupArgs, mi_gemm_grouped.hip) -- every per-problem quantity (descriptors, leading dimensions, K-tile count, alpha, output) is
+// carried per stage cursor / per epilogue frame and switched at tile boundaries.
 // ABL: 0 = product, 1 = no stores, 2 = clock stamps (dbg u64[4 * grid]), 3 = no epilogue at all (timing: wrong results),
 // 4 / 5 / 6 = plain (write-back) / nt / sc1+nt epilogue stores instead of sc1 (timing A/B of the store policy),
 // 7 = workgroup 0 stamps s_memtime at the start of every K-tile (dbg u64[1024]: the per-K-tile timeline around tile boundaries)
-template <int FA, int FB, int ABL>
-__global__ __launch_bounds__(256, 1) void gemm_w4p(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
-                                                   uint16_t* __restrict__ D, const float* __restrict__ sa_inv,
-                                                   const float* __restrict__ sb_inv, int K, int lda, int ldb, int ldd,
-                                                   int tiles_m, int tiles_n, int a_bytes, int b_bytes, int d_bytes,
-                                                   unsigned long long* __restrict__ dbg) {
+template <int FA, int FB, int ABL, int MODE>
+__global__ __launch_bounds__(256, 1) void gemm_w4p(const std::conditional_t<MODE == 2, GroupArgs, W4Single> ka) {
+  constexpr bool GROUPED = MODE == 2, BIAS = MODE == 1;
   constexpr int S = 3;  // phase schedule (w4::sched_*)
   static_assert(w4::sched_lag(S) == 2, "the cursor logic below assumes every stage of step s goes to step s + 2");
+  static_assert(!(GROUPED && ABL != 0), "the grouped form has no timing builds");
   __shared__ __attribute__((aligned(16))) uint8_t lds[kLdsBytes + (ABL == 7 ? 8192 : 0)];
   int stamp_idx = 0;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
-  const int ntiles = tiles_m * tiles_n, G = gridDim.x, bid = blockIdx.x;
-  const int my_tiles = (ntiles - bid + G - 1) / G;  // tiles bid, bid + G, ... (host: <= 64 per workgroup)
-  const int nk = K / BK;                            // host: even, >= 4
-  const int total = my_tiles * nk;
-  const rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
-  const rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
-  const rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)D, 0, d_bytes, 0x00020000);
-  const float alpha = (*sa_inv) * (*sb_inv);
+  const int G = gridDim.x, bid = blockIdx.x;
 
-  // lane i keeps the (tile row | tile column << 16) of this workgroup's i-th tile: one vector evaluation of the tile map
-  int tab;
-  {
+  // ---- this workgroup's tiles: lane i of `tab` keeps tile row | tile column << 14 | problem << 28 of its i-th tile (<= 64)
+  int my_tiles = 0, tab = 0;
+  float alpha_of[kMaxGroup] = {1.f, 1.f, 1.f, 1.f};  // read ONCE: a memory read inside the tile walk would drain the LDS-DMA pipeline
+  if constexpr (GROUPED) {
+    // virtual index: XCD-major order of the workgroups (round-robin dispatch over the 8 XCDs: bid & 7 names the L2)
+    const int q8 = G >> 3, r8 = G & 7, xcd = bid & 7;
+    const int v = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    int my_cnt[kMaxGroup];
+#pragma unroll
+    for (int q = 0; q < kMaxGroup; ++q) {
+      my_cnt[q] = q < ka.n ? (int)ka.cnt[q][v] : 0;
+      my_tiles += my_cnt[q];
+      float a = 1.0f;
+      if (q < ka.n) a = (*ka.p[q].sa_inv) * (*ka.p[q].sb_inv);
+      alpha_of[q] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a)));
+    }
+    // pass 1 (uniform loop over my tiles): the tile's id within its problem = R[p][j] + rank of v among the workgroups that have a
+    // j-th tile of p (ballots over the 256-entry count table); pass 2 (one vector evaluation): id -> (tm, tn) in the grouped order
+    int my_id = 0, my_p = 0, ti = 0;
+#pragma unroll
+    for (int q = 0; q < kMaxGroup; ++q) {
+      if (q < ka.n) {
+        const unsigned c4 = reinterpret_cast<const unsigned*>(ka.cnt[q])[lane];  // counts of virtual workgroups 4 l .. 4 l + 3
+        for (int j = 0; j < my_cnt[q]; ++j, ++ti) {
+          int rank = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const bool f = (int)((c4 >> (8 * k)) & 255u) > j && (4 * lane + k) < v;
+            rank += __builtin_popcountll(__builtin_amdgcn_ballot_w64(f));
+          }
+          if (lane == ti) {
+            my_id = (int)ka.R[q][j] + rank;
+            my_p = q;
+          }
+        }
+      }
+    }
+    int tmn = ka.p[0].tiles_m, tnn = ka.p[0].tiles_n;
+#pragma unroll
+    for (int q = 1; q < kMaxGroup; ++q) {
+      const bool is = my_p == q;
+      tmn = is ? ka.p[q].tiles_m : tmn;
+      tnn = is ? ka.p[q].tiles_n : tnn;
+    }
     int tm, tn;
-    tile_of_block(bid + min(lane, max(my_tiles - 1, 0)) * G, ntiles, tiles_m, tiles_n, tm, tn);
-    tab = tm | (tn << 16);
+    tile_of_flat(my_id, max(tmn, 1), max(tnn, 1), tm, tn);
+    tab = tm | (tn << 14) | (my_p << 28);
+  } else {
+    const int ntiles = ka.tiles_m * ka.tiles_n;
+    my_tiles = (ntiles - bid + G - 1) / G;  // tiles bid, bid + G, ... (host: <= 64 per workgroup)
+    int tm, tn;
+    tile_of_block(bid + min(lane, max(my_tiles - 1, 0)) * G, ntiles, ka.tiles_m, ka.tiles_n, tm, tn);
+    tab = tm | (tn << 14);
+    alpha_of[0] = (*ka.sa_inv) * (*ka.sb_inv);
   }
-  auto tile_rc = [&](int ti, int& ra, int& rb) __attribute__((always_inline)) {
+  auto tile_of = [&](int ti, int& p, int& ra, int& rb) __attribute__((always_inline)) {
     const int t = __builtin_amdgcn_readlane(tab, ti);
-    ra = (t & 0xFFFF) * 256;
-    rb = (int)((unsigned)t >> 16) * 256;
-  };
-  auto tile_d_off = [&](int ti) -> int {
-    int ra, rb;
-    tile_rc(ti, ra, rb);
-    return (ra * ldd + rb) * 2;
+    p = (t >> 28) & 3;
+    ra = (t & 0x3FFF) * 256;
+    rb = ((t >> 14) & 0x3FFF) * 256;
   };
 
-  int a_v, b_v;
-  {
-    const int lr = lane >> 3, lc = lane & 7;
-    const int chunk = (lc ^ swz_f(lr)) * 16;
-    const int row = (wave >> 1) * 128 + (wave & 1) * 32 + lr;
-    a_v = row * lda + chunk;
-    b_v = row * ldb + chunk;
-  }
   uint8_t* const buf0 = lds;
   uint8_t* const buf1 = lds + kBufBytes;
   auto dma = [&](rsrc_t rs, uint8_t* dst, int voff, int soff) __attribute__((always_inline)) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(dst), 16, voff, soff, 0, 0);
   };
-  // stage cursor: wave-uniform (tile origin, K offset) of step s + 2, clamped to the last step
+  // stage cursor: wave-uniform (problem, tile origin, K offset) of step s + 2, clamped to the last step.  a_v / b_v: per-lane
+  // byte offset row * ld + chunk of the wave's first piece (they depend on the problem's leading dimensions)
   struct cursor_t {
-    int oa, ob, kb, ti, kt, step;
+    int oa, ob, kb, ti, kt, nk, lda, ldb, a_v, b_v, step;
+    rsrc_t rsA, rsB;
   };
-  auto cursor_at_tile = [&](cursor_t& c) __attribute__((always_inline)) {
-    int ra, rb;
-    tile_rc(c.ti, ra, rb);
-    c.oa = ra * lda;
-    c.ob = rb * ldb;
+  auto enter_tile = [&](cursor_t& c, int ti) __attribute__((always_inline)) {
+    int p, ra, rb;
+    tile_of(ti, p, ra, rb);
+    if constexpr (GROUPED) {
+      const GroupProblem& P = ka.p[p];
+      c.nk = P.nk;
+      c.lda = P.lda;
+      c.ldb = P.ldb;
+      c.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A, 0, P.a_bytes, 0x00020000);
+      c.rsB = __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, P.b_bytes, 0x00020000);
+      int ln;
+      asm volatile("v_mov_b32 %0, %1" : "=v"(ln) : "v"(lane));  // (not hoisted: nothing of this stays live across the K loop)
+      const int lr = ln >> 3, chunk = ((ln & 7) ^ swz_f(lr)) * 16;
+      const int row = (wave >> 1) * 128 + (wave & 1) * 32 + lr;
+      c.a_v = row * P.lda + chunk;
+      c.b_v = row * P.ldb + chunk;
+    }
+    c.oa = ra * c.lda;
+    c.ob = rb * c.ldb;
   };
-  // branch-free (a branch costs ~31 cycles at one wave per SIMD, and the cursor moves once per K-tile): selects only
+  int total = 0;  // steps of this workgroup (one-problem forms)
   auto advance = [&](cursor_t& c) __attribute__((always_inline)) {
-    const int more = (c.step + 1 < total) ? 1 : 0;
-    c.step += more;
-    const int kt1 = c.kt + more;
-    const int wrap = (kt1 == nk) ? 1 : 0;
-    c.kt = wrap ? 0 : kt1;
-    c.kb = wrap ? 0 : c.kb + more * BK;
-    c.ti += wrap;
-    cursor_at_tile(c);
+    if constexpr (GROUPED) {
+      // the tile switch reloads the problem's descriptors: a wave-uniform branch, taken once per tile (no MFMA inside)
+      const bool wrap = c.kt + 1 == c.nk;
+      if (wrap && c.ti + 1 < my_tiles) {
+        c.ti += 1;
+        c.kt = 0;
+        c.kb = 0;
+        enter_tile(c, c.ti);
+      } else {
+        const int inc = wrap ? 0 : 1;
+        c.kt += inc;
+        c.kb += inc * BK;
+      }
+    } else {
+      // branch-free (a branch costs ~31 cycles at one wave per SIMD, and the cursor moves once per K-tile): selects only
+      const int more = (c.step + 1 < total) ? 1 : 0;
+      c.step += more;
+      const int kt1 = c.kt + more;
+      const int wrap = (kt1 == c.nk) ? 1 : 0;
+      c.kt = wrap ? 0 : kt1;
+      c.kb = wrap ? 0 : c.kb + more * BK;
+      c.ti += wrap;
+      enter_tile(c, c.ti);
+    }
   };
   auto stage_a = [&](int h, const cursor_t& c, uint8_t* buf, int p) __attribute__((always_inline)) {
-    dma(rsA, buf + (h ? kOffA1 : kOffA0) + (wave * 4 + p) * 1024, a_v, c.oa + c.kb + (h * 64 + p * 8) * lda);
+    dma(c.rsA, buf + (h ? kOffA1 : kOffA0) + (wave * 4 + p) * 1024, c.a_v, c.oa + c.kb + (h * 64 + p * 8) * c.lda);
   };
   auto stage_b = [&](int h, const cursor_t& c, uint8_t* buf, int p) __attribute__((always_inline)) {
-    dma(rsB, buf + (h ? kOffB1 : kOffB0) + (wave * 4 + p) * 1024, b_v, c.ob + c.kb + (h * 64 + p * 8) * ldb);
+    dma(c.rsB, buf + (h ? kOffB1 : kOffB0) + (wave * 4 + p) * 1024, c.b_v, c.ob + c.kb + (h * 64 + p * 8) * c.ldb);
   };
 
   int fa_lo[2], fa_hi[2], fb_lo[2], fb_hi[2];
@@ -470,16 +545,56 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p(const uint8_t* __restrict__ A
   int unit = kUnitScale;
   asm volatile("" : "+v"(unit));
 
-  // ---- epilogue (see the header)
-  const int fr = lane & 15, fq = lane >> 4;
-  const int ecol = (fq & 1) * 16 + (fq >> 1) * 8;  // column of this lane's 8-wide piece inside a 32-column block after the swap
-  // whole-line stores: lane (m = fr, q) of line half 0 covers row m & 7, of half 1 row 8 + (m & 7); lanes m >= 8 carry block 1
-  const int d_voff = ((wr * 128 + (fr & 7)) * ldd + wc * 128 + (fr >> 3) * 32 + ecol) * 2;
+  // ---- epilogue (see the header).  An epilogue frame belongs to ONE tile: its output descriptor, offset, leading dimension and
+  // alpha travel in `epi_t` (the LAST K-tile runs the tile's own frame, the next tile's FIRST / SECOND K-tiles finish it)
+  struct epi_t {
+    rsrc_t rs;
+    int d_off, ldd, d_voff;
+    float alpha;
+  };
+  auto epi_of = [&](int ti, bool real) __attribute__((always_inline)) -> epi_t {
+    int p, ra, rb;
+    tile_of(ti, p, ra, rb);
+    epi_t e;
+    uint16_t* Dp;
+    int d_bytes;
+    if constexpr (GROUPED) {
+      const GroupProblem& P = ka.p[p];
+      Dp = P.D;
+      d_bytes = P.d_bytes;
+      e.ldd = P.ldd;
+      e.alpha = p == 0 ? alpha_of[0] : p == 1 ? alpha_of[1] : p == 2 ? alpha_of[2] : alpha_of[3];
+    } else {
+      Dp = ka.D;
+      d_bytes = ka.d_bytes;
+      e.ldd = ka.ldd;
+      e.alpha = alpha_of[0];
+    }
+    // no previous tile: a descriptor of zero records (the address check drops the stores)
+    e.rs = __builtin_amdgcn_make_buffer_rsrc((void*)Dp, 0, real ? d_bytes : 0, 0x00020000);
+    e.d_off = (ra * e.ldd + rb) * 2;
+    int ln;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(ln) : "v"(lane));
+    const int fr = ln & 15, fq = ln >> 4;
+    const int ecol = (fq & 1) * 16 + (fq >> 1) * 8;  // column of this lane's 8-wide piece inside a 32-column block after the swap
+    // whole-line stores: lane (m = fr, q) of line half 0 covers row m & 7, of half 1 row 8 + (m & 7); lanes m >= 8 carry block 1
+    e.d_voff = ((wr * 128 + (fr & 7)) * e.ldd + wc * 128 + (fr >> 3) * 32 + ecol) * 2;
+    return e;
+  };
   v4i park[w4::kPark][2];
 #pragma unroll
   for (int i = 0; i < w4::kPark; ++i) park[i][0] = park[i][1] = (v4i){0, 0, 0, 0};
+  // BIAS: this lane's 4 bias values (packed bf16) for each of the 8 accumulator-tile columns (B half b, fragment j) of the CURRENT
+  // tile, loaded in the tile's SECOND K-tile (after the previous tile's conversions, >= 9 phases before the first use, so the
+  // counted waits of the phases in between retire them: vmcnt retires in order)
+  typedef unsigned int v2u_ __attribute__((ext_vector_type(2)));
+  v2u_ bias_w[2][4];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias_w[b][j] = (v2u_){0u, 0u};
   u32 px = 0, py = 0;
-  auto conv_chunk = [&](auto r_c, auto sub_c) __attribute__((always_inline)) {
+  auto conv_chunk = [&](auto r_c, auto sub_c, const epi_t& e) __attribute__((always_inline)) {
     constexpr int r = decltype(r_c)::value, sub = decltype(sub_c)::value;
     constexpr int q = r >> 2, a = q >> 1, b = (q == 1 || q == 2) ? 1 : 0, i = r & 3;  // Q00, Q01, Q11, Q10
     v4i& e0 = park[r % w4::kPark][0];
@@ -488,7 +603,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p(const uint8_t* __restrict__ A
       // the AGPR -> VGPR copy of an asm output is placed at its DEFINITION (right behind the tile's last MFMA), i.e. a whole
       // quadrant would sit in 64 VGPRs until its chunks come up; passing the tile through an empty asm here pins the copy here
       asm volatile("" : "+a"(acc[a][b][i][sub]));
-      const v4f v = acc[a][b][i][sub] * alpha;
+      v4f v = acc[a][b][i][sub] * e.alpha;
+      if constexpr (BIAS) {
+        v[0] += __uint_as_float(bias_w[b][sub].x << 16);
+        v[1] += __uint_as_float(bias_w[b][sub].x & 0xFFFF0000u);
+        v[2] += __uint_as_float(bias_w[b][sub].y << 16);
+        v[3] += __uint_as_float(bias_w[b][sub].y & 0xFFFF0000u);
+      }
       const u32 x = pack_bf16x2(v[0], v[1]), y = pack_bf16x2(v[2], v[3]);
       if constexpr ((sub & 1) == 0) {
         px = x;
@@ -502,17 +623,17 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p(const uint8_t* __restrict__ A
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int keep = e1[e];
-        e1[e] = __builtin_amdgcn_update_dpp(e1[e], e0[e], 0x128, 0xF, 0x3, false);  // rows m < 8  <- block 0 of row m + 8
-        e0[e] = __builtin_amdgcn_update_dpp(e0[e], keep, 0x128, 0xF, 0xC, false);   // rows m >= 8 <- block 1 of row m - 8
+      for (int k = 0; k < 4; ++k) {
+        const int keep = e1[k];
+        e1[k] = __builtin_amdgcn_update_dpp(e1[k], e0[k], 0x128, 0xF, 0x3, false);  // rows m < 8  <- block 0 of row m + 8
+        e0[k] = __builtin_amdgcn_update_dpp(e0[k], keep, 0x128, 0xF, 0xC, false);   // rows m >= 8 <- block 1 of row m - 8
       }
     }
   };
-  auto store_event = [&](auto e_c, auto w_c, int d_tile, rsrc_t rsOut) __attribute__((always_inline)) {
-    constexpr int e = decltype(e_c)::value, r = e >> 1, half = e & 1, w = decltype(w_c)::value;
+  auto store_event = [&](auto e_c, auto w_c, const epi_t& e) __attribute__((always_inline)) {
+    constexpr int ev = decltype(e_c)::value, r = ev >> 1, half = ev & 1, w = decltype(w_c)::value;
     constexpr int q = r >> 2, a = q >> 1, b = (q == 1 || q == 2) ? 1 : 0, i = r & 3;
-    const int rowoff = d_tile + ((a * 64 + i * 16 + half * 8) * ldd + b * 64) * 2;
+    const int rowoff = e.d_off + ((a * 64 + i * 16 + half * 8) * e.ldd + b * 64) * 2;
     const v4i data = park[r % w4::kPark][half];
     if (ABL == 1) {
       asm volatile("" ::"v"(data));
@@ -523,32 +644,48 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p(const uint8_t* __restrict__ A
       // the store alone sits behind a wave-uniform branch (never an MFMA or a conversion micro-op: branches around those make
       // hipcc spill accumulators / fragments)
       if (wave == w) {
-        __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)data, rsOut, d_voff, rowoff, kAux);
+        __builtin_amdgcn_raw_buffer_store_b128((mi::v4u)data, e.rs, e.d_voff, rowoff, kAux);
         asm volatile("s_nop 1" ::"v"(data) : "memory");
       }
     }
   };
   // everything the epilogue does in frame slot g (after that slot's MFMA)
-  auto epi_slot = [&](auto g_c, int d_tile, rsrc_t rsOut) __attribute__((always_inline)) {
+  auto epi_slot = [&](auto g_c, const epi_t& e) __attribute__((always_inline)) {
     constexpr int g = decltype(g_c)::value;
     if constexpr (ABL != 3) {
       static_for<16>([&](auto r_c) __attribute__((always_inline)) {
         constexpr int r = decltype(r_c)::value, cs = w4::conv_start(r);
-        if constexpr (g >= cs && g < cs + 5) conv_chunk(r_c, std::integral_constant<int, g - cs>{});
+        if constexpr (g >= cs && g < cs + 5) conv_chunk(r_c, std::integral_constant<int, g - cs>{}, e);
       });
       if constexpr (g >= w4::store_slot(0) && g < w4::kFrameSlots)
-        store_event(std::integral_constant<int, (g - w4::store_slot(0)) / 4>{}, std::integral_constant<int, (g - w4::store_slot(0)) % 4>{}, d_tile, rsOut);
+        store_event(std::integral_constant<int, (g - w4::store_slot(0)) / 4>{}, std::integral_constant<int, (g - w4::store_slot(0)) % 4>{}, e);
+    }
+  };
+  rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)lds, 0, 0, 0x00020000);
+  if constexpr (BIAS) rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)ka.bias, 0, ka.n_cols * 2, 0x00020000);
+  auto load_bias = [&](int rb) __attribute__((always_inline)) {  // 8 loads of 8 bytes per lane; reads past N return 0 (range check)
+    if constexpr (BIAS) {
+      const int voff = (wc * 128 + (lane >> 4) * 4) * 2;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          bias_w[b][j] = __builtin_bit_cast(v2u_, __builtin_amdgcn_raw_buffer_load_b64(rsBias, voff, rb * 2 + (b * 64 + j * 16) * 2, 0));
     }
   };
 
   cursor_t c2;
-  // d_tile / rsOut: output of the tile whose frame this K-tile belongs to (LAST: this tile; FIRST, SECOND: the previous one)
+  // e: the frame this K-tile works on (LAST: this tile's; FIRST, SECOND: the previous tile's); rb_cur: first column of the current tile
   auto phase = [&](auto mode_c, auto p_c, const v8i (&af)[4], const v8i (&bf)[4], v4f (&c)[4][4], auto stage, auto read,
-                   int d_tile, rsrc_t rsOut) __attribute__((always_inline)) {
-    constexpr int MODE = decltype(mode_c)::value, P = decltype(p_c)::value;
-    constexpr bool ZC = MODE == w4::FIRST;
+                   const epi_t& e, int rb_cur) __attribute__((always_inline)) {
+    constexpr int MODE_ = decltype(mode_c)::value, P = decltype(p_c)::value;
+    constexpr bool ZC = MODE_ == w4::FIRST;
     constexpr bool NOST = ABL == 1 || ABL == 3;
-    constexpr int X = (NOST || MODE == w4::MID) ? 0 : w4::wait_x(MODE + P);
+    // younger ops a wait must allow besides the 20 LDS-DMA of the five later stages: the stores, and (BIAS) the 8 bias loads
+    // issued in p0 of the SECOND K-tile (frame phase 8), for the five phases that follow it
+    constexpr int G_ = MODE_ + P;
+    constexpr int XB = (BIAS && MODE_ != w4::MID && G_ >= 9 && G_ <= 13) ? 8 : 0;
+    constexpr int X = ((NOST || MODE_ == w4::MID) ? 0 : w4::wait_x(G_)) + XB;
     static_assert(20 + X <= 63, "vmcnt is a 6-bit counter");
     __builtin_amdgcn_sched_barrier(0);
     static_for<16>([&](auto k_c) __attribute__((always_inline)) {
@@ -559,6 +696,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p(const uint8_t* __restrict__ A
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(8)" ::"n"(20 + X) : "memory");
         __builtin_amdgcn_s_barrier();
+        if constexpr (BIAS && MODE_ == w4::SECOND && P == 0) load_bias(rb_cur);
       }
 #pragma unroll
       for (int p = 0; p < 4; ++p)
@@ -566,7 +704,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p(const uint8_t* __restrict__ A
 #pragma unroll
       for (int n = 0; n < 8; ++n)
         if (k == w4::sched_rd(S, n)) read(n);
-      if constexpr (MODE != w4::MID && MODE != w4::THIRD) epi_slot(std::integral_constant<int, 16 * (MODE + P) + k>{}, d_tile, rsOut);
+      if constexpr (MODE_ != w4::MID && MODE_ != w4::THIRD) epi_slot(std::integral_constant<int, 16 * (MODE_ + P) + k>{}, e);
       __builtin_amdgcn_sched_barrier(0);
     });
   };
@@ -574,7 +712,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p(const uint8_t* __restrict__ A
   using p1_t = std::integral_constant<int, 1>;
   using p2_t = std::integral_constant<int, 2>;
   using p3_t = std::integral_constant<int, 3>;
-  auto ktile = [&](auto mode_c, auto par_c, int d_tile, rsrc_t rsOut) __attribute__((always_inline)) {
+  auto ktile = [&](auto mode_c, auto par_c, const epi_t& e, int rb_cur) __attribute__((always_inline)) {
     constexpr int par = decltype(par_c)::value;
     uint8_t* const cur = par ? buf1 : buf0;
     if (ABL == 7) {
@@ -585,20 +723,32 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p(const uint8_t* __restrict__ A
       ++stamp_idx;
     }
     phase(mode_c, p0_t{}, aA, b0[par], acc[0][0], [&](int p) __attribute__((always_inline)) { stage_a(0, c2, cur, p); },
-          [&](int n) __attribute__((always_inline)) { read_part(b1, fb_lo[par], fb_hi[par], 1, n); }, d_tile, rsOut);
+          [&](int n) __attribute__((always_inline)) { read_part(b1, fb_lo[par], fb_hi[par], 1, n); }, e, rb_cur);
     phase(mode_c, p1_t{}, aA, b1, acc[0][1], [&](int p) __attribute__((always_inline)) { stage_b(0, c2, cur, p); },
-          [&](int n) __attribute__((always_inline)) { read_part(aB, fa_lo[par], fa_hi[par], 1, n); }, d_tile, rsOut);
+          [&](int n) __attribute__((always_inline)) { read_part(aB, fa_lo[par], fa_hi[par], 1, n); }, e, rb_cur);
     phase(mode_c, p2_t{}, aB, b1, acc[1][1], [&](int p) __attribute__((always_inline)) { stage_b(1, c2, cur, p); },
-          [&](int n) __attribute__((always_inline)) { read_part(aA, fa_lo[par ^ 1], fa_hi[par ^ 1], 0, n); }, d_tile, rsOut);
+          [&](int n) __attribute__((always_inline)) { read_part(aA, fa_lo[par ^ 1], fa_hi[par ^ 1], 0, n); }, e, rb_cur);
     phase(mode_c, p3_t{}, aB, b0[par], acc[1][0], [&](int p) __attribute__((always_inline)) { stage_a(1, c2, cur, p); },
-          [&](int n) __attribute__((always_inline)) { read_part(b0[par ^ 1], fb_lo[par ^ 1], fb_hi[par ^ 1], 0, n); }, d_tile, rsOut);
+          [&](int n) __attribute__((always_inline)) { read_part(b0[par ^ 1], fb_lo[par ^ 1], fb_hi[par ^ 1], 0, n); }, e, rb_cur);
     advance(c2);
   };
 
   if (my_tiles <= 0) return;
   // prologue: steps 0 and 1 in the steady-state stage order, with the two read-only phases p2(-1), p3(-1) woven in
   c2.ti = 0; c2.kt = 0; c2.kb = 0; c2.step = 0;
-  cursor_at_tile(c2);
+  if constexpr (!GROUPED) {
+    c2.nk = ka.K / BK;
+    c2.lda = ka.lda;
+    c2.ldb = ka.ldb;
+    c2.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)ka.A, 0, ka.a_bytes, 0x00020000);
+    c2.rsB = __builtin_amdgcn_make_buffer_rsrc((void*)ka.B, 0, ka.b_bytes, 0x00020000);
+    const int lr = lane >> 3, chunk = ((lane & 7) ^ swz_f(lr)) * 16;
+    const int row = (wave >> 1) * 128 + (wave & 1) * 32 + lr;
+    c2.a_v = row * ka.lda + chunk;
+    c2.b_v = row * ka.ldb + chunk;
+    total = my_tiles * c2.nk;
+  }
+  enter_tile(c2, 0);
   auto stage4a = [&](int h, uint8_t* buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) stage_a(h, c2, buf, p);
@@ -639,67 +789,90 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p(const uint8_t* __restrict__ A
   using second_t = std::integral_constant<int, w4::SECOND>;
   using third_t = std::integral_constant<int, w4::THIRD>;
   using last_t = std::integral_constant<int, w4::LAST>;
-  int d_prev = 0;
+  epi_t ep_prev = epi_of(0, false);
+  int steps_done = 0;
   for (int ti = 0; ti < my_tiles; ++ti) {
-    const int d_cur = tile_d_off(ti);
-    // descriptor for the PREVIOUS tile's frame: zero records while there is no previous tile (stores dropped)
-    const rsrc_t rsPrev = __builtin_amdgcn_make_buffer_rsrc((void*)D, 0, ti > 0 ? d_bytes : 0, 0x00020000);
-    ktile(first_t{}, par0_t{}, d_prev, rsPrev);
-    ktile(second_t{}, par1_t{}, d_prev, rsPrev);
-    ktile(third_t{}, par0_t{}, 0, rsD);
-    for (int pair = 2; pair < nk / 2; ++pair) {
-      ktile(mid_t{}, par1_t{}, 0, rsD);
-      ktile(mid_t{}, par0_t{}, 0, rsD);
+    const epi_t ep_cur = epi_of(ti, true);
+    int p_, ra_, rb_cur;
+    tile_of(ti, p_, ra_, rb_cur);
+    int nk_t;
+    if constexpr (GROUPED) nk_t = ka.p[p_].nk;
+    else nk_t = ka.K / BK;
+    ktile(first_t{}, par0_t{}, ep_prev, rb_cur);
+    ktile(second_t{}, par1_t{}, ep_prev, rb_cur);
+    ktile(third_t{}, par0_t{}, ep_cur, rb_cur);
+    for (int pair = 2; pair < nk_t / 2; ++pair) {
+      ktile(mid_t{}, par1_t{}, ep_cur, rb_cur);
+      ktile(mid_t{}, par0_t{}, ep_cur, rb_cur);
     }
-    ktile(last_t{}, par1_t{}, d_cur, rsD);
-    d_prev = d_cur;
+    ktile(last_t{}, par1_t{}, ep_cur, rb_cur);
+    ep_prev = ep_cur;
+    steps_done += nk_t;
   }
   if (ABL == 2) {
     const unsigned long long ck1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
     if (tid == 0) {
-      unsigned long long* o = dbg + (size_t)bid * 4;
-      o[0] = ck1 - ck0;
-      o[1] = rt1 - rt0;
-      o[2] = (unsigned long long)total;
-      o[3] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+      if constexpr (!GROUPED) {
+        unsigned long long* o = ka.dbg + (size_t)bid * 4;
+        o[0] = ck1 - ck0;
+        o[1] = rt1 - rt0;
+        o[2] = (unsigned long long)steps_done;
+        o[3] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+      }
     }
   }
   if (ABL == 7) {
     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
-    if (bid == 0 && wave == 0) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      for (int i = lane; i < 1024; i += 64)
-        dbg[i] = i < stamp_idx ? reinterpret_cast<unsigned long long*>(lds + kLdsBytes)[i] : (i == stamp_idx ? t_end : 0ull);
+    if constexpr (!GROUPED) {
+      if (bid == 0 && wave == 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int i = lane; i < 1024; i += 64)
+          ka.dbg[i] = i < stamp_idx ? reinterpret_cast<unsigned long long*>(lds + kLdsBytes)[i] : (i == stamp_idx ? t_end : 0ull);
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // tail prefetches retired; last MFMAs written back
   // the rest of the last tile's frame
   static_for<w4::kFrameSlots - 64>([&](auto g_c) __attribute__((always_inline)) {
-    epi_slot(std::integral_constant<int, 64 + decltype(g_c)::value>{}, d_prev, rsD);
+    epi_slot(std::integral_constant<int, 64 + decltype(g_c)::value>{}, ep_prev);
     __builtin_amdgcn_sched_barrier(0);
   });
 }
 
 template <int FA, int FB>
 static int launch_w4_fmt(const uint8_t* a, const uint8_t* b, uint16_t* D, const float* sa_inv, const float* sb_inv, int64_t M,
-                         int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int variant, void* dbg, hipStream_t st) {
+                         int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int variant, void* dbg, hipStream_t st,
+                         const void* bias) {
   const int tiles_m = (int)(M / 256), tiles_n = (int)(N / 256);
   const dim3 grid(tiles_m * tiles_n), block(256);
 #define MI_W4(ABLv)                                                                                                      \
   hipLaunchKernelGGL((gemm_w4<FA, FB, ABLv>), grid, block, 0, st, a, b, D, sa_inv, sb_inv, (int)K, (int)lda, (int)ldb,    \
                      (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb), (int)(M * ldd * 2), (unsigned long long*)dbg)
-#define MI_W4P(ABLv)                                                                                                     \
-  hipLaunchKernelGGL((gemm_w4p<FA, FB, ABLv>), pgrid, block, 0, st, a, b, D, sa_inv, sb_inv, (int)K, (int)lda, (int)ldb,  \
-                     (int)ldd, tiles_m, tiles_n, (int)(M * lda), (int)(N * ldb), (int)(M * ldd * 2), (unsigned long long*)dbg)
+  W4Single ws;
+  ws.A = a; ws.B = b; ws.D = D; ws.sa_inv = sa_inv; ws.sb_inv = sb_inv; ws.bias = (const uint16_t*)bias; ws.dbg = (unsigned long long*)dbg;
+  ws.K = (int)K; ws.lda = (int)lda; ws.ldb = (int)ldb; ws.ldd = (int)ldd; ws.tiles_m = tiles_m; ws.tiles_n = tiles_n;
+  ws.a_bytes = (int)(M * lda); ws.b_bytes = (int)(N * ldb); ws.d_bytes = (int)(M * ldd * 2); ws.n_cols = (int)N;
+#define MI_W4P(ABLv) hipLaunchKernelGGL((gemm_w4p<FA, FB, ABLv, 0>), pgrid, block, 0, st, ws)
   const int ntiles = tiles_m * tiles_n;
   const dim3 pgrid(ntiles < num_cus() ? ntiles : num_cus());
-  if (variant >= 10 && variant < 20 && ((ntiles + (int)pgrid.x - 1) / (int)pgrid.x > 64 || K < 512)) {
-    set_error("mi_gemm (w4 persistent): needs K >= 512 and at most 64 tiles per workgroup");
+  if (variant >= 10 && variant < 20 && ((ntiles + (int)pgrid.x - 1) / (int)pgrid.x > 64 || K < 512 || tiles_m >= 16384 || tiles_n >= 16384)) {
+    set_error("mi_gemm (w4 persistent): needs K >= 512, at most 64 tiles per workgroup and fewer than 16384 tiles per dimension");
     return MI_ERR_SHAPE;
   }
+  if (bias != nullptr && variant != 10) {
+    set_error("mi_gemm (w4): only the persistent product kernel takes a bias");
+    return MI_ERR_ARG;
+  }
   if (variant == 0) MI_W4(0);
+  else if (variant == 10 && bias != nullptr) hipLaunchKernelGGL((gemm_w4p<FA, FB, 0, 1>), pgrid, block, 0, st, ws);
   else if (variant == 10) MI_W4P(0);
-  else if (variant == 12) MI_W4P(2);
+  else if (variant == 12) {
+    if constexpr (FA == 0 && FB == 0) MI_W4P(2);
+    else {
+      set_error("mi_gemm (w4): the clock-stamp build is E4M3 x E4M3 only");
+      return MI_ERR_ARG;
+    }
+  }
 #ifdef MI_DIAG
   else if (variant == 1) MI_W4(1);
   else if (variant == 2) MI_W4(2);
@@ -724,12 +897,18 @@ static int launch_w4_fmt(const uint8_t* a, const uint8_t* b, uint16_t* D, const 
     }
   }
 #undef MI_W4S
-  else if (variant == 11) MI_W4P(1);
-  else if (variant == 13) MI_W4P(3);
-  else if (variant == 14) MI_W4P(4);
-  else if (variant == 15) MI_W4P(5);
-  else if (variant == 16) MI_W4P(6);
-  else if (variant == 17) MI_W4P(7);
+  else if ((variant == 11 || (variant >= 13 && variant <= 17)) && !(FA == 0 && FB == 0)) {
+    set_error("mi_gemm (w4): timing variant %d is built for E4M3 x E4M3 only", variant);
+    return MI_ERR_ARG;
+  }
+#define MI_W4P_LAB(ABLv) do { if constexpr (FA == 0 && FB == 0) MI_W4P(ABLv); } while (0)
+  else if (variant == 11) MI_W4P_LAB(1);
+  else if (variant == 13) MI_W4P_LAB(3);
+  else if (variant == 14) MI_W4P_LAB(4);
+  else if (variant == 15) MI_W4P_LAB(5);
+  else if (variant == 16) MI_W4P_LAB(6);
+  else if (variant == 17) MI_W4P_LAB(7);
+#undef MI_W4P_LAB
 #endif
   else {
     set_error("mi_gemm (w4): variant %d is a timing build of the lab library", variant);
@@ -745,13 +924,28 @@ static int launch_w4_fmt(const uint8_t* a, const uint8_t* b, uint16_t* D, const 
 // 10 = product, 11 = no stores, 12 = clock stamps (dbg = u64[4 * grid]), 13 = no epilogue.  Shapes: M, N % 256 == 0, K % 256 == 0,
 // operands below 2 GiB (the dispatcher in mi_gemm.hip checks).
 int launch_w4(const void* A, const void* B, void* D, const float* sa_inv, const float* sb_inv, int64_t M, int64_t N, int64_t K,
-              int64_t lda, int64_t ldb, int64_t ldd, int fa, int fb, int variant, void* dbg, hipStream_t st) {
+              int64_t lda, int64_t ldb, int64_t ldd, int fa, int fb, int variant, void* dbg, hipStream_t st, const void* bias) {
   const uint8_t *a = (const uint8_t*)A, *b = (const uint8_t*)B;
   uint16_t* d = (uint16_t*)D;
-  if (fa == 0 && fb == 0) return launch_w4_fmt<0, 0>(a, b, d, sa_inv, sb_inv, M, N, K, lda, ldb, ldd, variant, dbg, st);
-  if (fa == 0 && fb == 1) return launch_w4_fmt<0, 1>(a, b, d, sa_inv, sb_inv, M, N, K, lda, ldb, ldd, variant, dbg, st);
-  if (fa == 1 && fb == 0) return launch_w4_fmt<1, 0>(a, b, d, sa_inv, sb_inv, M, N, K, lda, ldb, ldd, variant, dbg, st);
-  return launch_w4_fmt<1, 1>(a, b, d, sa_inv, sb_inv, M, N, K, lda, ldb, ldd, variant, dbg, st);
+  if (fa == 0 && fb == 0) return launch_w4_fmt<0, 0>(a, b, d, sa_inv, sb_inv, M, N, K, lda, ldb, ldd, variant, dbg, st, bias);
+  if (fa == 0 && fb == 1) return launch_w4_fmt<0, 1>(a, b, d, sa_inv, sb_inv, M, N, K, lda, ldb, ldd, variant, dbg, st, bias);
+  if (fa == 1 && fb == 0) return launch_w4_fmt<1, 0>(a, b, d, sa_inv, sb_inv, M, N, K, lda, ldb, ldd, variant, dbg, st, bias);
+  return launch_w4_fmt<1, 1>(a, b, d, sa_inv, sb_inv, M, N, K, lda, ldb, ldd, variant, dbg, st, bias);
+}
+
+// grouped launch (mi_gemm_fp8_grouped, tile_cfg 4): the schedule in `ga` is the eight-wave kernel's (256 x 256 tiles)
+int launch_w4_grouped(const GroupArgs& ga, int fa, int fb, int grid, hipStream_t st) {
+  for (int q = 0; q < ga.n; ++q)
+    if (ga.p[q].nk < 4 || (ga.p[q].nk & 1)) {
+      set_error("mi_gemm_fp8_grouped (four-wave kernel): every problem needs K >= 512 and K %% 256 == 0");
+      return MI_ERR_SHAPE;
+    }
+  if (fa == 0 && fb == 0) hipLaunchKernelGGL((gemm_w4p<0, 0, 0, 2>), dim3(grid), dim3(256), 0, st, ga);
+  else if (fa == 0 && fb == 1) hipLaunchKernelGGL((gemm_w4p<0, 1, 0, 2>), dim3(grid), dim3(256), 0, st, ga);
+  else if (fa == 1 && fb == 0) hipLaunchKernelGGL((gemm_w4p<1, 0, 0, 2>), dim3(grid), dim3(256), 0, st, ga);
+  else hipLaunchKernelGGL((gemm_w4p<1, 1, 0, 2>), dim3(grid), dim3(256), 0, st, ga);
+  MI_CHECK_LAUNCH("mi_gemm_fp8_grouped (four-wave) launch");
+  return MI_OK;
 }
 
 }  // namespace mi

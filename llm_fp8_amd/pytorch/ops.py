@@ -438,7 +438,7 @@ def grouped_gemm_choice(problems, fmt_a: int, fmt_b: int) -> int:
 
 def grouped_gemm_autotune(problems, fmt_a: int, fmt_b: int, iters: int = 3) -> int:
     """Measured choice for a recurring group of GEMMs (a Linear's dgrad + wgrad): -1 = separate launches, 0-3 = one grouped launch
-    with that tile shape.  Timed once per (shapes, formats) on the operands at hand but into SCRATCH outputs (the live dX buffer and
+    with that tile shape, 4 = one grouped launch of 256 x 256 tiles on the four-wave kernel.  Timed once per (shapes, formats) on the operands at hand but into SCRATCH outputs (the live dX buffer and
     gradient-arena slot are not touched), and cached.  The model (grouped_gemm_plan) ranks the same candidates from counts alone;
     the measurement also sees what the model leaves out (per-tile epilogue cost, L2 behaviour, clock)."""
     shapes = tuple((a.shape[0], b.shape[0], a.shape[1]) for a, b, _, _, _ in problems)
@@ -452,6 +452,8 @@ def grouped_gemm_autotune(problems, fmt_a: int, fmt_b: int, iters: int = 3) -> i
         for cfg, (bm, bn) in enumerate(_TILE_CFGS):
             if all(M % bm == 0 and N % bn == 0 for M, N, K in shapes):
                 cands[cfg] = cfg
+        if all(M % 256 == 0 and N % 256 == 0 and K >= 512 for M, N, K in shapes) and os.environ.get("LLM_FP8_AMD_GEMM_W4G", "1") != "0":
+            cands[4] = 4  # 256 x 256 tiles on the four-wave kernel (mi_gemm_w4.hip)
 
     def run(c):
         if c == -1:

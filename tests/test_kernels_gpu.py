@@ -185,7 +185,7 @@ def test_gemm_fp8_vs_oracle(ops, dev, shape, fa, fb, algo):
     sa, sb = np.float32(1 / 7.3), np.float32(1 / 0.011)
     rng = np.random.default_rng(3)
     bias = O.f32_to_bf16_bits(rng.normal(size=N).astype(np.float32) * 10)
-    for use_bias in ((False,) if algo in (6, 9) else (False, True)):  # the four-wave kernels take no bias
+    for use_bias in ((False,) if algo == 6 else (False, True)):  # of the four-wave kernels only the persistent one takes a bias
         ref = O.gemm_fp8_tn(a8, b8, fa, fb, sa, sb, bias if use_bias else None, out_f32=True)
         d = ops.gemm_fp8(torch.from_numpy(a8).to(dev), torch.from_numpy(b8).to(dev), _f32(sa, dev), _f32(sb, dev),
                          fa, fb, bias=bits_to_bf16(bias, dev) if use_bias else None, algo=algo)
@@ -928,6 +928,8 @@ def test_mxfp8_full_size_properties(ops, dev):
 
 # ----------------------------------------------------------------------------------------- grouped GEMM (dgrad + wgrad in one launch)
 GROUPS = [
+    [(512, 768, 512), (768, 512, 512)],                       # small pair the four-wave kernel takes too (K = 512: FIRST, SECOND, THIRD, LAST only)
+    [(2048, 1024, 768), (1024, 768, 2048), (512, 512, 1280)],  # three problems, K-tile counts 6, 16, 10, on both kernels
     [(512, 768, 256), (768, 256, 512)],                       # a Linear's dgrad [M,K_w] and wgrad [N_w,K_w]: K 256 vs 512
     [(2048, 768, 1024), (1024, 768, 2048)],                   # 192-column tiles
     [(4096, 3072, 3072), (3072, 3072, 4096)],                 # o-proj backward at M = 4096: > 1 round, mixed K
@@ -957,13 +959,15 @@ def test_grouped_gemm_is_bitwise_the_separate_launches(ops, dev, group, fa, fb):
         out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
         probs.append((a8, b8, sa, sb, out))
     ops.gemm_fp8_grouped(probs, fa, fb)
-    for cfg in (-1, 3):  # the chosen tile shape and, where it divides everything, the 192 x 192 one
+    for cfg in (-1, 3, 4):  # the chosen tile shape; where it divides everything the 192 x 192 one; the four-wave kernel (256 x 256, K >= 512)
         if cfg == 3 and any(M % 192 or N % 192 for M, N, K in group):
             continue
-        if cfg == 3:
+        if cfg == 4 and any(M % 256 or N % 256 or K < 512 for M, N, K in group):
+            continue
+        if cfg >= 3:
             for p in probs:
                 p[4].fill_(float("nan"))
-            ops.gemm_fp8_grouped(probs, fa, fb, tile_cfg=3)
+            ops.gemm_fp8_grouped(probs, fa, fb, tile_cfg=cfg)
         for (a8, b8, sa, sb, out), (M, N, K) in zip(probs, group):
             alone = ops.gemm_fp8(a8, b8, sa, sb, fa, fb, algo=4)
             assert torch.equal(out.view(torch.int16), alone.view(torch.int16)), f"problem {M}x{N}x{K} (tile cfg {cfg}) differs from its own launch"

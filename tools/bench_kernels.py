@@ -315,11 +315,17 @@ def main():
                     ops.gemm_fp8(g8t, x8t, one, one, 0, 0, out=dw, algo=4)
                 def grp():
                     ops.gemm_fp8_grouped([(g8, w8t, one, one, dx), (g8t, x8t, one, one, dw)], 0, 0)
-                res = time_interleaved({"separate": sep, "grouped": grp}, rounds=10, inner=4)
+                def grp4():
+                    ops.gemm_fp8_grouped([(g8, w8t, one, one, dx), (g8t, x8t, one, one, dw)], 0, 0, tile_cfg=4)
+                cands = {"separate": sep, "grouped": grp}
+                if M % 256 == 0 and N % 256 == 0 and K % 256 == 0:
+                    cands["grouped_w4"] = grp4
+                res = time_interleaved(cands, rounds=10, inner=4)
                 fl = 4.0 * M * N * K
                 tsep += res["separate"]; tgrp += res["grouped"]
                 print(f"grouped {mname} {name:7s} bwd M={M} N={N} K={K}: separate {res['separate']*1e6:7.1f} us {fl/res['separate']/1e12:6.0f} TF   "
-                      f"grouped {res['grouped']*1e6:7.1f} us {fl/res['grouped']/1e12:6.0f} TF   {res['separate']/res['grouped']:.3f}x", flush=True)
+                      f"grouped {res['grouped']*1e6:7.1f} us {fl/res['grouped']/1e12:6.0f} TF   {res['separate']/res['grouped']:.3f}x"
+                      + (f"   grouped_w4 {res['grouped_w4']*1e6:7.1f} us {fl/res['grouped_w4']/1e12:6.0f} TF   {res['grouped']/res['grouped_w4']:.3f}x vs grouped" if "grouped_w4" in res else ""), flush=True)
             print(f"grouped {mname} total: separate {tsep*1e6:8.1f} us  grouped {tgrp*1e6:8.1f} us  {tsep/tgrp:.3f}x", flush=True)
     if "clock" in args.which:
         from llm_fp8_amd import _lib

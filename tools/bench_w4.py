@@ -55,6 +55,17 @@ def main():
                     ok = torch.equal(r4, got)
                     print(f"parity {name:10s} {m}x{n}x{k} algo {al} fmt {fa}{fb}: {'bitwise = algo 4' if ok else 'MISMATCH max|d| ' + str((r4.float() - got.float()).abs().max().item())}", flush=True)
                     assert ok
+    if "bias" in args.which:  # the persistent four-wave kernel with a bias against the eight-wave kernel with the same bias: bitwise, then timing
+        for name, m, n, k in shapes:
+            a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
+            bias = (torch.randn(n, device=dev, generator=g) * 3).to(torch.bfloat16)
+            sc = torch.tensor([0.37], device=dev)
+            ref = ops.gemm_fp8(a, b, sc, one, 0, 0, bias=bias, algo=4)
+            got = ops.gemm_fp8(a, b, sc, one, 0, 0, bias=bias, algo=9)
+            assert torch.equal(ref, got), f"bias: algo 9 differs from algo 4 on {name}: {(ref.float() - got.float()).abs().max().item()}"
+            out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+            res = time_interleaved({al: (lambda al=al: ops.gemm_fp8(a, b, one, one, 0, 0, bias=bias, out=out, algo=al)) for al in (4, 9)}, rounds=8, inner=5)
+            print(f"bias {name:10s} {m}x{n}x{k}: bitwise ok;  " + "  ".join(f"a{al}: {t*1e6:7.1f} us {2.0*m*n*k/t/1e12:5.0f} TF" for al, t in res.items()), flush=True)
     if "timing" in args.which:
         algos = [int(x) for x in args.algos.split(",")]
         tot = {al: 0.0 for al in algos}
