@@ -56,8 +56,9 @@ extern "C" {
  *   2  round 2: mi_gemm_fp8 algo values 20-30, 46 (diagnostic builds), mi_adamw_cast_bf16_multi, mi_transpose_u8,
  *      mi_gemm_fp8_grouped
  *   3  round 2: mi_adamw_mxcast_bf16_multi
- *   4  round 3: diagnostic algo values and mi_attn_fwd_diag moved out (lab build, -DMI_DIAG); mi_gemm_fp8 algos 6 and 9
- *      (four-wave kernel); mi_gemm_fp8_clock
+ *   4  round 3: diagnostic algo values and mi_attn_fwd_diag moved out (lab build, -DMI_DIAG); mi_gemm_fp8 algos 6, 9, 47 and
+ *      mi_gemm_fp8_grouped tile_cfg 4 (four-wave kernel); mi_gemm_fp8_clock; mi_swiglu_cast_bias, mi_dswiglu_cast_bias,
+ *      mi_add_bias_rmsnorm_stats (bias fused into the consumer of the GEMM output)
  */
 #define MI_ABI_VERSION 4
 int mi_abi_version(void);
@@ -257,6 +258,13 @@ int mi_swiglu_cast(const void* h_bf16, void* y_fp8, void* yT_fp8, const float* s
  */
 int mi_dswiglu_cast(const void* h_bf16, const void* dact_bf16, void* y_fp8, void* yT_fp8, const float* scale,
                     float* amax, float* colsum, int64_t rows, int64_t F, int fmt, void* stream);
+/* The two SwiGLU kernels with the fc1 bias (bf16 [2F], 16-byte aligned) added to `h` INSIDE the kernel, in fp32, before the
+ * activation: `h` is then the fc1 GEMM's output WITHOUT its bias.  TE's bias + activation fusion (LayerNormMLP keeps TE's default
+ * bias=True on the reference path, te_llama.py:58-63): the add rides in an HBM-bound kernel instead of in the GEMM epilogue. */
+int mi_swiglu_cast_bias(const void* h_bf16, const void* bias_bf16, void* y_fp8, void* yT_fp8, const float* scale, float* amax,
+                        int64_t rows, int64_t F, int fmt, void* stream);
+int mi_dswiglu_cast_bias(const void* h_bf16, const void* bias_bf16, const void* dact_bf16, void* y_fp8, void* yT_fp8,
+                         const float* scale, float* amax, float* colsum, int64_t rows, int64_t F, int fmt, void* stream);
 
 /*
  * K9  RMSNorm fused with the FP8 cast of the following GEMM's input  [TE LayerNormLinear / LayerNormMLP with
@@ -272,6 +280,10 @@ int mi_rmsnorm_stats(const void* x_bf16, float* rstd, int64_t rows, int64_t cols
  * layer (te_llama.py:78,81) fused with the statistics pass of the RMSNorm that consumes it. */
 int mi_add_rmsnorm_stats(const void* a_bf16, const void* b_bf16, void* out_bf16, float* rstd, int64_t rows, int64_t cols,
                          float eps, void* stream);
+/* mi_add_rmsnorm_stats with a bias (bf16 [cols]) on the second addend: out = a + (b + bias) -- `b` is the fc2 GEMM's output without
+ * its bias, which joins the residual add it feeds anyway. */
+int mi_add_bias_rmsnorm_stats(const void* a_bf16, const void* b_bf16, const void* bias_bf16, void* out_bf16, float* rstd,
+                              int64_t rows, int64_t cols, float eps, void* stream);
 int mi_norm_cast(const void* x_bf16, const float* rstd, const void* gamma_bf16, void* y_fp8, void* yT_fp8,
                  const float* scale, float* amax, int64_t rows, int64_t cols, int fmt, void* stream);
 int mi_rmsnorm_bwd(const void* dy_bf16, const void* x_bf16, const float* rstd, const void* gamma_bf16,

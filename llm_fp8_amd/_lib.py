@@ -73,6 +73,9 @@ SIGNATURES = {
     "mi_mxfp8_swiglu_quantize": [_p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],
     "mi_mxfp8_dswiglu_quantize": [_p, _p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],
     "mi_gemm_mxfp8": [_p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_int, _p],
+    "mi_swiglu_cast_bias": [_p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],
+    "mi_dswiglu_cast_bias": [_p, _p, _p, _p, _p, _p, _p, _p, _c_i64, _c_i64, _c_int, _p],
+    "mi_add_bias_rmsnorm_stats": [_p, _p, _p, _p, _p, _c_i64, _c_i64, ctypes.c_float, _p],
     "mi_gemm_fp8_clock": [_p, _p, _p, _p, _p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_int, _p, _p],
 }
 # entry points only the lab build exports (#ifdef MI_DIAG in include/mi_fp8.h)

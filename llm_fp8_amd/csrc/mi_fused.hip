@@ -194,11 +194,15 @@ __device__ __forceinline__ float sigmoidf_(float g) { return 1.0f / (1.0f + __ex
 //               handled in two passes of 4 (pinned with sched_barrier): 151 us instead of 170 us per 8192x16384 (forcing
 //               128 VGPRs for a 4th wave per SIMD spills and doubles the time).
 //               colsum[(tile_r), c] = sum over the tile's 128 rows of val (fp32): fc1 bias gradient.
+//               `bias` (optional, bf16 [2F]): h holds the fc1 GEMM's output WITHOUT its bias and the bias is added here, in fp32,
+//               to the unpacked gate / up values (TE's bias + activation fusion: the add rides in an HBM-bound kernel whose VALU
+//               is idle instead of in the GEMM epilogue, where it costs 12 % of the K = 3072 GEMM).
 template <int FMT, int MODE, bool WRITE_Y, bool WRITE_T>
 __global__ __launch_bounds__(256) void swiglu_cast_kernel(const uint16_t* __restrict__ h, const uint16_t* __restrict__ d,
                                                           uint8_t* __restrict__ y, uint8_t* __restrict__ yT,
                                                           const float* __restrict__ scale_p, float* amax_out,
-                                                          float* __restrict__ colsum, int rows, int F, int tiles_c) {
+                                                          float* __restrict__ colsum, int rows, int F, int tiles_c,
+                                                          const uint16_t* __restrict__ bias) {
   __shared__ float s_amax[4];
   __shared__ float s_col[MODE == 1 ? 2 : 1][2][128];
   constexpr int NOUT = MODE == 0 ? 1 : 2;
@@ -217,6 +221,17 @@ __global__ __launch_bounds__(256) void swiglu_cast_kernel(const uint16_t* __rest
   const bool active = (r0 < rows) && (cg < F);
   if (active) {
     u32 lo[NOUT][8], hi[NOUT][8];
+    float bg[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, bu[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr) {
+      const v4i vg = *reinterpret_cast<const v4i*>(bias + cg), vu = *reinterpret_cast<const v4i*>(bias + F + cg);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bg[2 * j] = __uint_as_float((u32)vg[j] << 16);
+        bg[2 * j + 1] = __uint_as_float((u32)vg[j] & 0xFFFF0000u);
+        bu[2 * j] = __uint_as_float((u32)vu[j] << 16);
+        bu[2 * j + 1] = __uint_as_float((u32)vu[j] & 0xFFFF0000u);
+      }
+    }
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       v4i gv[4], uv[4], dv[4];
@@ -233,9 +248,15 @@ __global__ __launch_bounds__(256) void swiglu_cast_kernel(const uint16_t* __rest
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const u32 wg = (u32)gv[i][j], wu = (u32)uv[i][j], wd = (u32)dv[i][j];
-          const float g2[2] = {__uint_as_float(wg << 16), __uint_as_float(wg & 0xFFFF0000u)};
-          const float u2[2] = {__uint_as_float(wu << 16), __uint_as_float(wu & 0xFFFF0000u)};
+          float g2[2] = {__uint_as_float(wg << 16), __uint_as_float(wg & 0xFFFF0000u)};
+          float u2[2] = {__uint_as_float(wu << 16), __uint_as_float(wu & 0xFFFF0000u)};
           const float d2[2] = {__uint_as_float(wd << 16), __uint_as_float(wd & 0xFFFF0000u)};
+          if (bias != nullptr) {
+            g2[0] += bg[2 * j];
+            g2[1] += bg[2 * j + 1];
+            u2[0] += bu[2 * j];
+            u2[1] += bu[2 * j + 1];
+          }
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             const float sg = sigmoidf_(g2[e]);
@@ -315,19 +336,19 @@ __global__ __launch_bounds__(256) void swiglu_cast_kernel(const uint16_t* __rest
 
 template <int FMT, int MODE>
 static int launch_swiglu(const void* h, const void* d, void* y, void* yT, const float* scale, float* amax, float* colsum,
-                         int64_t rows, int64_t F, hipStream_t st) {
+                         int64_t rows, int64_t F, hipStream_t st, const void* bias = nullptr) {
   const int64_t ocols = MODE == 0 ? F : 2 * F;
   (void)ocols;
   const int tiles_r = (int)((rows + 127) / 128), tiles_c = (int)((F + 127) / 128);  // tiles of the [rows, F] gate space
   dim3 grid((unsigned)(tiles_r * tiles_c)), block(256);
-  const uint16_t *hp = (const uint16_t*)h, *dp = (const uint16_t*)d;
+  const uint16_t *hp = (const uint16_t*)h, *dp = (const uint16_t*)d, *bp = (const uint16_t*)bias;
   uint8_t *yp = (uint8_t*)y, *tp = (uint8_t*)yT;
   if (y && yT)
-    hipLaunchKernelGGL((swiglu_cast_kernel<FMT, MODE, true, true>), grid, block, 0, st, hp, dp, yp, tp, scale, amax, colsum, (int)rows, (int)F, tiles_c);
+    hipLaunchKernelGGL((swiglu_cast_kernel<FMT, MODE, true, true>), grid, block, 0, st, hp, dp, yp, tp, scale, amax, colsum, (int)rows, (int)F, tiles_c, bp);
   else if (y)
-    hipLaunchKernelGGL((swiglu_cast_kernel<FMT, MODE, true, false>), grid, block, 0, st, hp, dp, yp, tp, scale, amax, colsum, (int)rows, (int)F, tiles_c);
+    hipLaunchKernelGGL((swiglu_cast_kernel<FMT, MODE, true, false>), grid, block, 0, st, hp, dp, yp, tp, scale, amax, colsum, (int)rows, (int)F, tiles_c, bp);
   else
-    hipLaunchKernelGGL((swiglu_cast_kernel<FMT, MODE, false, true>), grid, block, 0, st, hp, dp, yp, tp, scale, amax, colsum, (int)rows, (int)F, tiles_c);
+    hipLaunchKernelGGL((swiglu_cast_kernel<FMT, MODE, false, true>), grid, block, 0, st, hp, dp, yp, tp, scale, amax, colsum, (int)rows, (int)F, tiles_c, bp);
   MI_CHECK_LAUNCH("mi_swiglu_cast launch");
   return MI_OK;
 }
@@ -780,12 +801,39 @@ extern "C" int mi_dswiglu_cast(const void* h_bf16, const void* dact_bf16, void* 
   return mi::launch_swiglu<MI_FMT_E5M2, 1>(h_bf16, dact_bf16, y_fp8, yT_fp8, scale, amax, colsum, rows, F, st);
 }
 
+// mi_swiglu_cast / mi_dswiglu_cast with the fc1 bias (bf16 [2F], 16-byte aligned) added to h inside the kernel: `h` is the fc1
+// GEMM's output WITHOUT bias (te_llama.py:58-63: LayerNormMLP keeps TE's default bias=True; TE's own bias + activation fusion)
+extern "C" int mi_swiglu_cast_bias(const void* h_bf16, const void* bias_bf16, void* y_fp8, void* yT_fp8, const float* scale, float* amax,
+                                   int64_t rows, int64_t F, int fmt, void* stream) {
+  int rc = swiglu_common_check("mi_swiglu_cast_bias", h_bf16, y_fp8, yT_fp8, scale, rows, F, fmt);
+  if (rc != MI_OK) return rc;
+  MI_CHECK_ARG(bias_bf16 && ((uintptr_t)bias_bf16 % 16) == 0, "mi_swiglu_cast_bias: bias must be non-null and 16-byte aligned");
+  if (rows == 0 || F == 0) return MI_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (fmt == MI_FMT_E4M3) return mi::launch_swiglu<MI_FMT_E4M3, 0>(h_bf16, nullptr, y_fp8, yT_fp8, scale, amax, nullptr, rows, F, st, bias_bf16);
+  return mi::launch_swiglu<MI_FMT_E5M2, 0>(h_bf16, nullptr, y_fp8, yT_fp8, scale, amax, nullptr, rows, F, st, bias_bf16);
+}
+
+extern "C" int mi_dswiglu_cast_bias(const void* h_bf16, const void* bias_bf16, const void* dact_bf16, void* y_fp8, void* yT_fp8,
+                                    const float* scale, float* amax, float* colsum, int64_t rows, int64_t F, int fmt, void* stream) {
+  int rc = swiglu_common_check("mi_dswiglu_cast_bias", h_bf16, y_fp8, yT_fp8, scale, rows, F, fmt);
+  if (rc != MI_OK) return rc;
+  MI_CHECK_ARG(dact_bf16 && ((uintptr_t)dact_bf16 % 16) == 0, "mi_dswiglu_cast_bias: dact must be non-null and 16-byte aligned");
+  MI_CHECK_ARG(bias_bf16 && ((uintptr_t)bias_bf16 % 16) == 0, "mi_dswiglu_cast_bias: bias must be non-null and 16-byte aligned");
+  if (rows == 0 || F == 0) return MI_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (fmt == MI_FMT_E4M3)
+    return mi::launch_swiglu<MI_FMT_E4M3, 1>(h_bf16, dact_bf16, y_fp8, yT_fp8, scale, amax, colsum, rows, F, st, bias_bf16);
+  return mi::launch_swiglu<MI_FMT_E5M2, 1>(h_bf16, dact_bf16, y_fp8, yT_fp8, scale, amax, colsum, rows, F, st, bias_bf16);
+}
+
 namespace mi {
 // out = a + b (fp32 sum, one bf16 rounding: what torch's bf16 add yields) and rstd of the ROUNDED sum in the same pass: the
 // residual add of a decoder layer feeds the next RMSNorm, whose statistics pass would re-read `out` from HBM.
+// `bias` (optional, bf16 [cols]): b is the fc2 GEMM's output WITHOUT its bias; out = a + (b + bias), the inner sum in fp32.
 __global__ __launch_bounds__(256) void add_rmsnorm_stats_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
                                                                 uint16_t* __restrict__ out, float* __restrict__ rstd, int rows,
-                                                                int cols, float eps) {
+                                                                int cols, float eps, const uint16_t* __restrict__ bias) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -794,12 +842,18 @@ __global__ __launch_bounds__(256) void add_rmsnorm_stats_kernel(const uint16_t* 
   for (int c = lane * 8; c < cols; c += 512) {
     const v4i va = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(a + off + c));
     const v4i vb = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(b + off + c));
+    v4i vbias = {0, 0, 0, 0};
+    if (bias != nullptr) vbias = *reinterpret_cast<const v4i*>(bias + c);
     v4i vo;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const u32 wa = (u32)va[j], wb = (u32)vb[j];
-      const u32 o = pack_bf16x2(__uint_as_float(wa << 16) + __uint_as_float(wb << 16),
-                                __uint_as_float(wa & 0xFFFF0000u) + __uint_as_float(wb & 0xFFFF0000u));
+      float b0 = __uint_as_float(wb << 16), b1 = __uint_as_float(wb & 0xFFFF0000u);
+      if (bias != nullptr) {
+        b0 += __uint_as_float((u32)vbias[j] << 16);
+        b1 += __uint_as_float((u32)vbias[j] & 0xFFFF0000u);
+      }
+      const u32 o = pack_bf16x2(__uint_as_float(wa << 16) + b0, __uint_as_float(wa & 0xFFFF0000u) + b1);
       const float lo = __uint_as_float(o << 16), hi = __uint_as_float(o & 0xFFFF0000u);
       acc += lo * lo + hi * hi;
       vo[j] = (int)o;
@@ -819,8 +873,23 @@ extern "C" int mi_add_rmsnorm_stats(const void* a_bf16, const void* b_bf16, void
   MI_CHECK_ARG((((uintptr_t)a_bf16 | (uintptr_t)b_bf16 | (uintptr_t)out_bf16) % 16) == 0, "mi_add_rmsnorm_stats: operands must be 16-byte aligned");
   if (rows == 0) return MI_OK;
   hipLaunchKernelGGL(mi::add_rmsnorm_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                     (const uint16_t*)a_bf16, (const uint16_t*)b_bf16, (uint16_t*)out_bf16, rstd, (int)rows, (int)cols, eps);
+                     (const uint16_t*)a_bf16, (const uint16_t*)b_bf16, (uint16_t*)out_bf16, rstd, (int)rows, (int)cols, eps,
+                     (const uint16_t*)nullptr);
   MI_CHECK_LAUNCH("mi_add_rmsnorm_stats launch");
+  return MI_OK;
+}
+
+extern "C" int mi_add_bias_rmsnorm_stats(const void* a_bf16, const void* b_bf16, const void* bias_bf16, void* out_bf16, float* rstd,
+                                         int64_t rows, int64_t cols, float eps, void* stream) {
+  MI_CHECK_ARG(a_bf16 && b_bf16 && bias_bf16 && out_bf16 && rstd, "mi_add_bias_rmsnorm_stats: null pointer");
+  MI_CHECK_ARG(rows >= 0 && cols > 0 && cols % 8 == 0 && rows < (1LL << 31) && cols < (1LL << 31), "mi_add_bias_rmsnorm_stats: bad shape");
+  MI_CHECK_ARG((((uintptr_t)a_bf16 | (uintptr_t)b_bf16 | (uintptr_t)out_bf16 | (uintptr_t)bias_bf16) % 16) == 0,
+               "mi_add_bias_rmsnorm_stats: operands must be 16-byte aligned");
+  if (rows == 0) return MI_OK;
+  hipLaunchKernelGGL(mi::add_rmsnorm_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)a_bf16, (const uint16_t*)b_bf16, (uint16_t*)out_bf16, rstd, (int)rows, (int)cols, eps,
+                     (const uint16_t*)bias_bf16);
+  MI_CHECK_LAUNCH("mi_add_bias_rmsnorm_stats launch");
   return MI_OK;
 }
 

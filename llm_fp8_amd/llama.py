@@ -150,10 +150,12 @@ class TELlamaDecoderLayer(torch.nn.Module):
                                                  _with_skip=True, _rstd=_handed_rstd(hidden_states))
         eps_mlp = self.layernorm_mlp.eps
         hidden_states, rstd = residual_add_stats(skip, attn_out, eps_mlp)
+        # `_defer_bias`: the fc2 bias (TE's default bias=True on LayerNormMLP, te_llama.py:58-63) joins the residual add below
+        # instead of the GEMM epilogue (TE's bias + activation fusion idea applied to both MLP biases)
         with te.fp8_autocast(enabled=fp8, fp8_recipe=self.mlp_recipe):
-            ffn_out, skip = self.layernorm_mlp(hidden_states, _with_skip=True, _rstd=(rstd, eps_mlp))
+            ffn_out, skip, ffn_bias = self.layernorm_mlp(hidden_states, _with_skip=True, _rstd=(rstd, eps_mlp), _defer_bias=True)
         eps_in = self.self_attention.layernorm_qkv.eps  # every decoder layer of a model shares rms_norm_eps
-        hidden_states, rstd = residual_add_stats(skip, ffn_out, eps_in)
+        hidden_states, rstd = residual_add_stats(skip, ffn_out, eps_in, bias=ffn_bias)
         if rstd is not None:
             hidden_states._mi_rstd = (rstd, eps_in, hidden_states._version)
         return hidden_states

@@ -89,11 +89,15 @@ def handoff_readers(t) -> bool:
 class _GemmSpec:
     """Everything non-tensor a GEMM site needs: recipe, meta windows, slot base, update trigger."""
     __slots__ = ("recipe", "meta_fwd", "meta_bwd", "g", "fmt_fwd", "fmt_bwd", "trigger_bwd_update", "training", "eps",
-                 "wcache", "first_mb", "with_skip", "rstd", "dy_handoff")
+                 "wcache", "first_mb", "with_skip", "rstd", "dy_handoff", "defer_bias")
 
     def __init__(self, recipe, meta_fwd, meta_bwd, g, trigger_bwd_update, training, eps=1e-5, wcache=None, first_mb=None,
-                 with_skip=False, rstd=None, dy_handoff=None):
+                 with_skip=False, rstd=None, dy_handoff=None, defer_bias=False):
         self.dy_handoff = dy_handoff
+        # LayerNormMLP (delayed scaling, fused SwiGLU): the fc1 bias is added inside the SwiGLU kernels (always, when there is
+        # one) and -- defer_bias -- the fc2 bias is left to the caller's residual add (residual_add_stats(..., bias=...)): TE's
+        # bias + activation fusion.  The bias add costs 12 % of a K = 3072 GEMM in its epilogue and nothing in an HBM-bound kernel.
+        self.defer_bias = defer_bias
         self.eps = eps
         # rstd: RMSNorm statistics of the input already computed by the producer of the input (residual_add_stats)
         self.rstd = rstd
@@ -135,6 +139,10 @@ class WeightSink:
 
     def mark(self) -> None:  # called by the optimiser after it rewrote every part in this step
         self.stamp = (tuple(w._version for w, _, _ in self.parts), self.arena.generation)
+
+
+# LLM_FP8_AMD_NO_MLP_BIAS_FUSION=1: keep both MLP biases in the GEMM epilogues (the round-2 behaviour; A/B switch)
+_FUSE_MLP_BIAS = os.environ.get("LLM_FP8_AMD_NO_MLP_BIAS_FUSION") != "1"
 
 
 def weight_sinks_enabled() -> bool:
@@ -298,24 +306,29 @@ def _mx_quantize_weights(weights, ns, N: int, K: int, fmt: int, colwise: bool):
 
 
 class _AddStatsFn(torch.autograd.Function):
-    """out = a + b and the RMSNorm statistics of `out` in one pass (mi_add_rmsnorm_stats)."""
+    """out = a + b (+ bias) and the RMSNorm statistics of `out` in one pass (mi_add_rmsnorm_stats / mi_add_bias_rmsnorm_stats).
+    `bias`: a detached tensor -- the gradient of a deferred bias is produced by the module that owns it (column sums of dy)."""
 
     @staticmethod
-    def forward(ctx, a, b, eps):
-        out, rstd = ops.add_rmsnorm_stats(a, b, eps)
+    def forward(ctx, a, b, eps, bias=None):
+        out, rstd = ops.add_rmsnorm_stats(a, b, eps, bias=bias)
         ctx.mark_non_differentiable(rstd)
         return out, rstd
 
     @staticmethod
     def backward(ctx, dout, _drstd):
-        return dout, dout, None
+        return dout, dout, None, None
 
 
-def residual_add_stats(a: torch.Tensor, b: torch.Tensor, eps: float):
-    """`a + b` for the residual stream, plus rstd (or None) for the RMSNorm that consumes the sum: (sum, rstd)."""
+def residual_add_stats(a: torch.Tensor, b: torch.Tensor, eps: float, bias: Optional[torch.Tensor] = None):
+    """`a + b` for the residual stream, plus rstd (or None) for the RMSNorm that consumes the sum: (sum, rstd).
+    `bias`: the deferred output bias of the module that produced `b` (LayerNormMLP(..., _defer_bias=True)): out = a + (b + bias)."""
     if (a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.shape == b.shape and a.is_contiguous()
-            and b.is_contiguous() and a.shape[-1] % 8 == 0):
-        return _AddStatsFn.apply(a, b, eps)
+            and b.is_contiguous() and a.shape[-1] % 8 == 0 and (bias is None or a.shape[-1] == bias.numel())):
+        bb = None if bias is None else bias.detach().to(torch.bfloat16).contiguous()
+        return _AddStatsFn.apply(a, b, eps, bb)
+    if bias is not None:
+        b = b + bias.detach().to(b.dtype)
     return a + b, None
 
 
@@ -539,12 +552,16 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
             x8, x8t = ops.cast_amax(x2, mf.scale(0), mf.amax(0), fmt, want_t=need_w)
         dev = x2.device
         w1_8, w1_8t, si1 = _cast_weights(spec, 0, (w1,), [w1.shape[0]], w1.shape[0], K, dev, bwd)
-        h = ops.gemm_fp8(x8, w1_8, mf.scale_inv(0), si1, fmt, fmt,
-                         bias=None if b1 is None else b1.to(torch.bfloat16).contiguous())
-        a8, a8t = ops.swiglu_cast(h, mf.scale(3), mf.amax(3), fmt, want_t=need_w)
+        # fc1: the GEMM leaves the bias out, the SwiGLU kernels add it (fp32) to the gate / up values they unpack anyway
+        b1_bf = None if b1 is None else b1.detach().to(torch.bfloat16).contiguous()
+        fuse_b1 = b1_bf is not None and _FUSE_MLP_BIAS and (b1_bf.data_ptr() % 16 == 0)
+        h = ops.gemm_fp8(x8, w1_8, mf.scale_inv(0), si1, fmt, fmt, bias=None if (b1_bf is None or fuse_b1) else b1_bf)
+        a8, a8t = ops.swiglu_cast(h, mf.scale(3), mf.amax(3), fmt, want_t=need_w, bias=b1_bf if fuse_b1 else None)
+        ctx.b1_fused = b1_bf if fuse_b1 else None
         w2_8, w2_8t, si2 = _cast_weights(spec, 1, (w2,), [w2.shape[0]], w2.shape[0], w2.shape[1], dev, bwd)
+        # fc2: with defer_bias the caller adds the bias in its residual add (LayerNormMLP.forward hands it over)
         y = ops.gemm_fp8(a8, w2_8, mf.scale_inv(3), si2, fmt, fmt,
-                         bias=None if b2 is None else b2.to(torch.bfloat16).contiguous())
+                         bias=None if (b2 is None or spec.defer_bias) else b2.to(torch.bfloat16).contiguous())
         snap = mf.scale_inv_snapshot() if bwd else None
         sinv = (snap[0:1], si1, snap[3:4], si2) if bwd else None  # scale_inv of x, w1, act, w2 as of quantisation time
         ctx.saved_fp8 = (x8t, w1_8t, a8t, w2_8t, h if bwd else None, sinv)
@@ -637,7 +654,7 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
         # dSwiGLU + cast of fc1's grad_output (GEMM index 0: bwd slot 0) + fc1 bias gradient
         want_b1 = ctx.dtypes[1] is not None
         dh8, dh8t, colsum = ops.dswiglu_cast(h, dact, mb.scale(0), mb.amax(0), fmt_b, want_y=ctx.need_dgrad,
-                                             want_t=ctx.need_w, want_colsum=want_b1)
+                                             want_t=ctx.need_w, want_colsum=want_b1, bias=getattr(ctx, "b1_fused", None))
         db1 = (colsum, ctx.dtypes[1]) if want_b1 else None
         dx, dw1 = _dgrad_wgrad(dh8, w1_8t, dh8t, x8t, mb.scale_inv(0), sinv[1], sinv[0], fmt_b, fmt_f,
                                 _wgrad_out(ctx.w_refs[:1], x8t.shape[0]) if ctx.need_w else None, ctx.need_dgrad, ctx.need_w)
@@ -953,17 +970,26 @@ class LayerNormMLP(_FP8Module):
             return _rmsnorm(x, self.layer_norm_weight, self.eps, self.zero_centered_gamma)
         return _layernorm(x, self.layer_norm_weight, self.layer_norm_bias, self.eps, self.zero_centered_gamma)
 
-    def forward(self, inp: torch.Tensor, is_first_microbatch=None, _with_skip: bool = False, _rstd=None):
+    def forward(self, inp: torch.Tensor, is_first_microbatch=None, _with_skip: bool = False, _rstd=None, _defer_bias: bool = False):
+        """`_defer_bias` (extension, with `_with_skip`): returns (out, skip, bias) where `out` lacks the fc2 bias and `bias` is the
+        tensor the caller must add (residual_add_stats(skip, out, eps, bias=bias)), or None when nothing was deferred."""
         if is_first_microbatch is None:
             is_first_microbatch = self.default_is_first_microbatch
         st = self._prepare(inp.device)
         if (st is not None and self.activation == "swiglu" and self.fused_swiglu and _can_fuse_norm(self, st[0], inp)):
             recipe, mf, mb, first = st  # K9 + K10: norm -> cast, fc1, SwiGLU -> cast, fc2 in one autograd node
-            return _FP8SwiGLUMLPFn.apply(inp, self.fc1_weight, self.fc1_bias, self.fc2_weight, self.fc2_bias,
-                                         _GemmSpec(recipe, mf, mb, 0, first, self.training, self.eps, self._wcache,
-                                                   is_first_microbatch, with_skip=_with_skip, rstd=_usable_rstd(_rstd, inp, self.eps)),
-                                         self.layer_norm_weight)
+            defer = bool(_defer_bias and _with_skip and _FUSE_MLP_BIAS and self.fc2_bias is not None and not recipe.mxfp8())
+            res = _FP8SwiGLUMLPFn.apply(inp, self.fc1_weight, self.fc1_bias, self.fc2_weight, self.fc2_bias,
+                                        _GemmSpec(recipe, mf, mb, 0, first, self.training, self.eps, self._wcache,
+                                                  is_first_microbatch, with_skip=_with_skip, rstd=_usable_rstd(_rstd, inp, self.eps),
+                                                  defer_bias=defer),
+                                        self.layer_norm_weight)
+            if _defer_bias and _with_skip:
+                return res[0], res[1], (self.fc2_bias if defer else None)
+            return res
         out = self._unfused(inp, st, is_first_microbatch)
+        if _defer_bias and _with_skip:
+            return out, inp, None
         return (out, inp) if _with_skip else out  # unfused route: the residual is the input itself
 
     def _unfused(self, inp, st, is_first_microbatch):

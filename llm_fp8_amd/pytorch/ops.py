@@ -546,29 +546,34 @@ def rope_qkv_backward_cast(dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor,
 
 
 def swiglu_cast(h: torch.Tensor, scale: torch.Tensor, amax: Optional[torch.Tensor], fmt: int, want_y: bool = True,
-                want_t: bool = True):
-    """K10 fwd.  h bf16 [R, 2F] -> (act8 [R, F], act8T [F, R]) with act = silu(gate) * up computed in fp32."""
-    _dev(h, scale, amax)
+                want_t: bool = True, bias: Optional[torch.Tensor] = None):
+    """K10 fwd.  h bf16 [R, 2F] -> (act8 [R, F], act8T [F, R]) with act = silu(gate) * up computed in fp32.
+    `bias` (bf16 [2F]): h is the fc1 output WITHOUT bias; the kernel adds it (fp32) before the activation."""
+    _dev(h, scale, amax, bias)
     assert h.dtype == torch.bfloat16 and h.dim() == 2 and h.is_contiguous() and h.shape[1] % 2 == 0
     R, F2 = h.shape
     F = F2 // 2
     y = torch.empty((R, F), dtype=torch.uint8, device=h.device) if want_y else None
     yT = torch.empty((F, R), dtype=torch.uint8, device=h.device) if want_t else None
-    args = (h.data_ptr(), _ptr(y), _ptr(yT), scale.data_ptr(), _ptr(amax), R, F, fmt, _stream())
+    if bias is None:
+        fn, args = _lib.load().mi_swiglu_cast, (h.data_ptr(), _ptr(y), _ptr(yT), scale.data_ptr(), _ptr(amax), R, F, fmt, _stream())
+    else:
+        assert bias.dtype == torch.bfloat16 and bias.numel() == F2 and bias.is_contiguous()
+        fn, args = _lib.load().mi_swiglu_cast_bias, (h.data_ptr(), bias.data_ptr(), _ptr(y), _ptr(yT), scale.data_ptr(), _ptr(amax), R, F, fmt, _stream())
     t = KernelTimer.active
     if t is None:
-        rc = _lib.load().mi_swiglu_cast(*args)
+        rc = fn(*args)
     else:
         with t.span("swiglu_cast", f"{R}x{F}", float(R * F), float(R * F * (4 + int(want_y) + int(want_t)))):
-            rc = _lib.load().mi_swiglu_cast(*args)
+            rc = fn(*args)
     _lib.check(rc, "mi_swiglu_cast")
     return y, yT
 
 
 def dswiglu_cast(h: torch.Tensor, dact: torch.Tensor, scale: torch.Tensor, amax: Optional[torch.Tensor], fmt: int,
-                 want_y: bool = True, want_t: bool = True, want_colsum: bool = False):
-    """K10 bwd.  -> (dh8 [R, 2F], dh8T [2F, R], colsum fp32 [ceil(R/128), 2F] or None)."""
-    _dev(h, dact, scale, amax)
+                 want_y: bool = True, want_t: bool = True, want_colsum: bool = False, bias: Optional[torch.Tensor] = None):
+    """K10 bwd.  -> (dh8 [R, 2F], dh8T [2F, R], colsum fp32 [ceil(R/128), 2F] or None).  `bias`: as swiglu_cast."""
+    _dev(h, dact, scale, amax, bias)
     assert h.dtype == torch.bfloat16 and dact.dtype == torch.bfloat16 and h.is_contiguous() and dact.is_contiguous()
     R, F2 = h.shape
     F = F2 // 2
@@ -576,13 +581,19 @@ def dswiglu_cast(h: torch.Tensor, dact: torch.Tensor, scale: torch.Tensor, amax:
     y = torch.empty((R, F2), dtype=torch.uint8, device=h.device) if want_y else None
     yT = torch.empty((F2, R), dtype=torch.uint8, device=h.device) if want_t else None
     cs = torch.empty(((R + 127) // 128, F2), dtype=torch.float32, device=h.device) if want_colsum else None
-    args = (h.data_ptr(), dact.data_ptr(), _ptr(y), _ptr(yT), scale.data_ptr(), _ptr(amax), _ptr(cs), R, F, fmt, _stream())
+    if bias is None:
+        fn = _lib.load().mi_dswiglu_cast
+        args = (h.data_ptr(), dact.data_ptr(), _ptr(y), _ptr(yT), scale.data_ptr(), _ptr(amax), _ptr(cs), R, F, fmt, _stream())
+    else:
+        assert bias.dtype == torch.bfloat16 and bias.numel() == F2 and bias.is_contiguous()
+        fn = _lib.load().mi_dswiglu_cast_bias
+        args = (h.data_ptr(), bias.data_ptr(), dact.data_ptr(), _ptr(y), _ptr(yT), scale.data_ptr(), _ptr(amax), _ptr(cs), R, F, fmt, _stream())
     t = KernelTimer.active
     if t is None:
-        rc = _lib.load().mi_dswiglu_cast(*args)
+        rc = fn(*args)
     else:
         with t.span("dswiglu_cast", f"{R}x{F}", float(R * F2), float(R * F * (6 + 2 * int(want_y) + 2 * int(want_t)))):
-            rc = _lib.load().mi_dswiglu_cast(*args)
+            rc = fn(*args)
     _lib.check(rc, "mi_dswiglu_cast")
     return y, yT, cs
 
@@ -597,16 +608,22 @@ def rmsnorm_stats(x: torch.Tensor, eps: float) -> torch.Tensor:
     return rstd
 
 
-def add_rmsnorm_stats(a: torch.Tensor, b: torch.Tensor, eps: float):
-    """(a + b [same shape, bf16], rstd fp32 [rows]) in one pass; rows = all leading dims, statistics over the last dim."""
-    _dev(a, b)
+def add_rmsnorm_stats(a: torch.Tensor, b: torch.Tensor, eps: float, bias: Optional[torch.Tensor] = None):
+    """(a + b [same shape, bf16], rstd fp32 [rows]) in one pass; rows = all leading dims, statistics over the last dim.
+    `bias` (bf16 [cols]): out = a + (b + bias) -- b is a GEMM output whose bias was left for this add."""
+    _dev(a, b, bias)
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
     C = a.shape[-1]
     R = a.numel() // C
     out = torch.empty_like(a)
     rstd = torch.empty(R, dtype=torch.float32, device=a.device)
-    _lib.check(_lib.load().mi_add_rmsnorm_stats(a.data_ptr(), b.data_ptr(), out.data_ptr(), rstd.data_ptr(), R, C, float(eps), _stream()),
-               "mi_add_rmsnorm_stats")
+    if bias is None:
+        rc = _lib.load().mi_add_rmsnorm_stats(a.data_ptr(), b.data_ptr(), out.data_ptr(), rstd.data_ptr(), R, C, float(eps), _stream())
+    else:
+        assert bias.dtype == torch.bfloat16 and bias.numel() == C and bias.is_contiguous()
+        rc = _lib.load().mi_add_bias_rmsnorm_stats(a.data_ptr(), b.data_ptr(), bias.data_ptr(), out.data_ptr(), rstd.data_ptr(), R, C,
+                                                   float(eps), _stream())
+    _lib.check(rc, "mi_add_rmsnorm_stats")
     return out, rstd
 
 

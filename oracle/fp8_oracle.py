@@ -372,9 +372,12 @@ def dswiglu_f32(h_bits: np.ndarray, dact_bits: np.ndarray) -> np.ndarray:
 # (v_exp_f32 of x * log2 e) and `rsqrtf` (v_rsq_f32) are accurate to a few ulps, numpy's exp / sqrt to <= 1 ulp.  The FP8
 # bytes of the fused kernels therefore equal the bytes of these values except where the value lies within a few float32
 # ulps of an FP8 rounding boundary -- the property tests/test_kernels_gpu.py asserts (fp8_mismatches_near_boundary).
-def swiglu_f32_device_order(h_bits: np.ndarray) -> np.ndarray:
-    """(g * sigmoid(g)) * u with sigmoid(g) = 1 / (1 + exp(-g)), all float32, left to right as in swiglu_cast_kernel MODE 0."""
+def swiglu_f32_device_order(h_bits: np.ndarray, bias_bits: np.ndarray = None) -> np.ndarray:
+    """(g * sigmoid(g)) * u with sigmoid(g) = 1 / (1 + exp(-g)), all float32, left to right as in swiglu_cast_kernel MODE 0.
+    `bias_bits` (bf16 [2F]): the fused-bias form -- one float32 add per element on the unpacked gate / up values first."""
     h = bf16_bits_to_f32(h_bits)
+    if bias_bits is not None:
+        h = (h + bf16_bits_to_f32(bias_bits)[None, :]).astype(np.float32)
     f = h.shape[1] // 2
     g, u = h[:, :f], h[:, f:]
     one = np.float32(1.0)
@@ -383,9 +386,12 @@ def swiglu_f32_device_order(h_bits: np.ndarray) -> np.ndarray:
     return ((g * sg) * u).astype(np.float32)
 
 
-def dswiglu_f32_device_order(h_bits: np.ndarray, dact_bits: np.ndarray) -> np.ndarray:
-    """[(d * u) * (sg * (1 + g * (1 - sg))) | d * (g * sg)] in float32, the grouping of swiglu_cast_kernel MODE 1."""
+def dswiglu_f32_device_order(h_bits: np.ndarray, dact_bits: np.ndarray, bias_bits: np.ndarray = None) -> np.ndarray:
+    """[(d * u) * (sg * (1 + g * (1 - sg))) | d * (g * sg)] in float32, the grouping of swiglu_cast_kernel MODE 1.
+    `bias_bits`: as swiglu_f32_device_order."""
     h = bf16_bits_to_f32(h_bits)
+    if bias_bits is not None:
+        h = (h + bf16_bits_to_f32(bias_bits)[None, :]).astype(np.float32)
     d = bf16_bits_to_f32(dact_bits)
     f = h.shape[1] // 2
     g, u = h[:, :f], h[:, f:]

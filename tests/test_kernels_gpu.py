@@ -350,6 +350,52 @@ def test_swiglu_cast_vs_oracle(ops, dev, shape, fmt):
 
 
 @pytest.mark.parametrize("shape", [(8, 8), (136, 72), (1024, 3072)])
+def test_swiglu_kernels_with_fused_bias_vs_oracle(ops, dev, shape):
+    """mi_swiglu_cast_bias / mi_dswiglu_cast_bias / mi_add_bias_rmsnorm_stats: the MLP biases added inside the consumer kernels
+    (TE's bias + activation fusion; LayerNormMLP keeps TE's default bias=True at te_llama.py:58-63).  Held to the float32
+    restatement in the device's operation order (one fp32 add on the unpacked values first): every mismatching byte must sit
+    within 2^-17 of a rounding boundary; with a ZERO bias the outputs are bit for bit those of the kernels without bias; the
+    residual add is exact (no transcendental): bytes identical to bf16(a + (b + bias))."""
+    R, F = shape
+    g = torch.Generator().manual_seed(R * 7 + F)
+    h = (torch.randn(R, 2 * F, generator=g) * 2).to(torch.bfloat16)
+    d = (torch.randn(R, F, generator=g) / 8).to(torch.bfloat16)
+    bias = (torch.randn(2 * F, generator=g) * 0.5).to(torch.bfloat16)
+    scale = np.float32(16.0)
+    amax = torch.zeros(1, dtype=torch.float32, device=dev)
+    y, yT = ops.swiglu_cast(h.to(dev), _f32(scale, dev), amax, O.E4M3, bias=bias.to(dev))
+    act32 = O.swiglu_f32_device_order(bf16_bits(h), bf16_bits(bias))
+    _assert_matches_fp32_restatement(u8(y), (act32 * scale).astype(np.float32), O.E4M3, "swiglu_cast + bias")
+    np.testing.assert_array_equal(u8(yT), u8(y).T)
+    np.testing.assert_allclose(amax.item(), np.abs(act32).max(), rtol=2e-6)
+    s2 = np.float32(64.0)
+    y2, y2T, cs = ops.dswiglu_cast(h.to(dev), d.to(dev), _f32(s2, dev), None, O.E5M2, want_colsum=True, bias=bias.to(dev))
+    dh32 = O.dswiglu_f32_device_order(bf16_bits(h), bf16_bits(d), bf16_bits(bias))
+    hb = (O.bf16_bits_to_f32(bf16_bits(h)) + O.bf16_bits_to_f32(bf16_bits(bias))[None, :]).astype(np.float32)
+    df = O.bf16_bits_to_f32(bf16_bits(d))
+    slack = np.concatenate([np.abs(df * hb[:, F:]) * s2 * 2.0 ** -21, np.zeros_like(df)], axis=1)
+    _assert_matches_fp32_restatement(u8(y2), (dh32 * s2).astype(np.float32), O.E5M2, "dswiglu_cast + bias", abs_slack=slack)
+    np.testing.assert_array_equal(u8(y2T), u8(y2).T)
+    np.testing.assert_allclose(cs.sum(0).cpu().numpy(), dh32.astype(np.float64).sum(0), rtol=1e-4, atol=1e-4 * np.abs(dh32).max() * np.sqrt(R))
+    zero = torch.zeros(2 * F, dtype=torch.bfloat16, device=dev)
+    a0, a0T = ops.swiglu_cast(h.to(dev), _f32(scale, dev), None, O.E4M3)
+    a1, a1T = ops.swiglu_cast(h.to(dev), _f32(scale, dev), None, O.E4M3, bias=zero)
+    assert torch.equal(a0, a1) and torch.equal(a0T, a1T)
+    # residual add with the fc2 bias: exact arithmetic
+    C = 2 * F if (2 * F) % 8 == 0 else 8
+    a = torch.randn(R, C, generator=g).to(torch.bfloat16)
+    b = torch.randn(R, C, generator=g).to(torch.bfloat16)
+    bb = (torch.randn(C, generator=g) * 0.1).to(torch.bfloat16)
+    out, rstd = ops.add_rmsnorm_stats(a.to(dev), b.to(dev), 1e-5, bias=bb.to(dev))
+    want = (a.float() + (b.float() + bb.float()[None, :])).to(torch.bfloat16)
+    assert torch.equal(out.cpu(), want)
+    out0, rstd0 = ops.add_rmsnorm_stats(a.to(dev), b.to(dev), 1e-5)
+    out1, rstd1 = ops.add_rmsnorm_stats(a.to(dev), b.to(dev), 1e-5, bias=torch.zeros(C, dtype=torch.bfloat16, device=dev))
+    assert torch.equal(out0, out1) and torch.equal(rstd0, rstd1)
+    np.testing.assert_allclose(rstd.cpu().numpy(), 1.0 / np.sqrt((want.float().numpy().astype(np.float64) ** 2).mean(1) + 1e-5), rtol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(8, 8), (136, 72), (1024, 3072)])
 def test_dswiglu_cast_vs_oracle(ops, dev, shape):
     R, F = shape
     g = torch.Generator().manual_seed(R * 3 + F)
