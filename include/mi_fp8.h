@@ -322,10 +322,11 @@ int mi_sumsq_bf16(const void* g_bf16, int64_t n, float* partial, int n_partials,
  * Multi-tensor forms: one launch for every tensor of a parameter group.  table [5, n_tensors] int64 ON THE DEVICE = rows of
  * p / g / exp_avg / exp_avg_sq addresses and element counts; chunks [n_chunks, 2] int32 on the device = (tensor index, chunk
  * index inside the tensor); each workgroup handles one chunk of chunk_elems (multiple of 8) elements.
- * mi_sumsq_bf16_multi writes partial[n_chunks] (fixed order: reproducible); mi_adamw_bf16_multi = mi_adamw_bf16 on every tensor.
+ * mi_sumsq_bf16_multi writes partial[n_chunks] in FLOAT64 (exact fp32 squares accumulated in fp64: the total is independent of the
+ * chunking and of how a caller groups or shards the tensors, to 2^-52); mi_adamw_bf16_multi = mi_adamw_bf16 on every tensor.
  */
 int mi_sumsq_bf16_multi(const int64_t* table, int n_tensors, const int32_t* chunks, int n_chunks, int chunk_elems,
-                        float* partial, void* stream);
+                        double* partial, void* stream);
 int mi_adamw_bf16_multi(const int64_t* table, int n_tensors, const int32_t* chunks, int n_chunks, int chunk_elems,
                         const float* grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay,
                         int64_t step, void* stream);

@@ -130,7 +130,9 @@ __global__ __launch_bounds__(256) void cast_amax_kernel(const uint16_t* __restri
     __syncthreads();
     if (tid == 0) {
       float m = fmaxf(fmaxf(s_amax[0], s_amax[1]), fmaxf(s_amax[2], s_amax[3]));
-      if (m > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(amax_out), __float_as_uint(m));
+      // only a workgroup that would raise the value goes to the atomic unit: same-address atomics are served one at a time and a
+      // wave cannot retire before its atomic has returned
+      if (m > 0.0f && m > __builtin_nontemporal_load(amax_out)) atomicMax(reinterpret_cast<unsigned int*>(amax_out), __float_as_uint(m));
     }
   }
 }
@@ -201,8 +203,11 @@ static int launch_cast(const void* x, void* y, void* yT, const float* scale, flo
                        int64_t cols, int64_t ld_y, int64_t ld_yT, hipStream_t st, float* colsum = nullptr) {
   const int tiles_r = (int)((rows + 63) / 64), tiles_c = (int)((cols + 63) / 64);
   const int64_t wgs = ((int64_t)tiles_r * tiles_c + 3) / 4;
-  const int64_t cap = (int64_t)cast_num_cus() * 3;  // what stays resident (3-4 waves per SIMD): 2-8 tiles per wave on the step's sizes
-  dim3 grid((unsigned)(wgs < cap ? wgs : cap)), block(256);
+  // two workgroups per CU, a whole multiple of the CU count: 8192 x 3072 takes 24.1 us with 512 workgroups, 26.2 with 768, 27-28 with
+  // 320-448 or 576-640 (uneven CU loads), 23.2 us one-shot but 26.3 when the amax slot starts at zero as it does in the step
+  // (profiles/r03_cast_grid_sweep.txt)
+  const int64_t cap2 = (int64_t)cast_num_cus() * 2;
+  dim3 grid((unsigned)(wgs < cap2 ? wgs : cap2)), block(256);
   const uint16_t* xp = (const uint16_t*)x;
   uint8_t *yp = (uint8_t*)y, *tp = (uint8_t*)yT;
   if (colsum) {

@@ -118,14 +118,18 @@ struct ChunkRef {
 };
 
 __global__ __launch_bounds__(256) void sumsq_multi_kernel(const int64_t* __restrict__ tab, int T, const ChunkRef* __restrict__ chunks,
-                                                          int chunk_elems, float* __restrict__ partial) {
-  __shared__ float s_red[4];
+                                                          int chunk_elems, double* __restrict__ partial) {
+  // The squares of bf16 values are exact in fp32 (8 x 8 significand bits); they are ACCUMULATED in fp64, so a chunk's partial does
+  // not depend on how the elements are dealt to lanes, and the total does not depend on how the tensors are cut into chunks,
+  // groups or row shards beyond 2^-52: distributed.ShardedFP8DP's clip coefficient is then the replicated run's, bit for bit
+  // (in fp32 the chunking moved the last bit of the norm in a few percent of the steps).  The kernel stays HBM-bound.
+  __shared__ double s_red[4];
   const ChunkRef cr = chunks[blockIdx.x];
   const uint16_t* g = reinterpret_cast<const uint16_t*>(tab[(int64_t)1 * T + cr.tensor]);
   const int64_t n = tab[(int64_t)4 * T + cr.tensor];
   const int64_t lo = (int64_t)cr.chunk * chunk_elems, hi = min(n, lo + chunk_elems);
   const int tid = threadIdx.x;
-  float acc0 = 0.0f, acc1 = 0.0f;
+  double acc0 = 0.0, acc1 = 0.0;
   if ((((uintptr_t)g) & 15) == 0) {  // chunk_elems is a multiple of 8: chunk starts stay 16-byte aligned
     const int64_t v0 = lo >> 3, v1 = hi >> 3;
     int64_t i = v0 + tid;
@@ -137,8 +141,8 @@ __global__ __launch_bounds__(256) void sumsq_multi_kernel(const int64_t* __restr
         const u32 wa = (u32)a[j], wb = (u32)b[j];
         const float a0 = __uint_as_float(wa << 16), a1 = __uint_as_float(wa & 0xFFFF0000u);
         const float b0 = __uint_as_float(wb << 16), b1 = __uint_as_float(wb & 0xFFFF0000u);
-        acc0 += a0 * a0 + a1 * a1;
-        acc1 += b0 * b0 + b1 * b1;
+        acc0 += (double)(a0 * a0) + (double)(a1 * a1);
+        acc1 += (double)(b0 * b0) + (double)(b1 * b1);
       }
     }
     for (; i < v1; i += 256) {
@@ -147,20 +151,20 @@ __global__ __launch_bounds__(256) void sumsq_multi_kernel(const int64_t* __restr
       for (int j = 0; j < 4; ++j) {
         const u32 wa = (u32)a[j];
         const float a0 = __uint_as_float(wa << 16), a1 = __uint_as_float(wa & 0xFFFF0000u);
-        acc0 += a0 * a0 + a1 * a1;
+        acc0 += (double)(a0 * a0) + (double)(a1 * a1);
       }
     }
     for (int64_t k = (v1 << 3) + tid; k < hi; k += 256) {
       const float a = bf16_bits_to_float(g[k]);
-      acc0 += a * a;
+      acc0 += (double)(a * a);
     }
   } else {
     for (int64_t k = lo + tid; k < hi; k += 256) {
       const float a = bf16_bits_to_float(g[k]);
-      acc0 += a * a;
+      acc0 += (double)(a * a);
     }
   }
-  float acc = acc0 + acc1;
+  double acc = acc0 + acc1;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
   if ((tid & 63) == 0) s_red[tid >> 6] = acc;
@@ -598,7 +602,7 @@ static mi::AdamArgs make_adam_args(float lr, float beta1, float beta2, float eps
 }
 
 extern "C" int mi_sumsq_bf16_multi(const int64_t* table, int n_tensors, const int32_t* chunks, int n_chunks, int chunk_elems,
-                                   float* partial, void* stream) {
+                                   double* partial, void* stream) {
   MI_CHECK_ARG(table && chunks && partial, "mi_sumsq_bf16_multi: null pointer");
   MI_CHECK_ARG(n_tensors >= 1 && n_chunks >= 1 && chunk_elems >= 8 && chunk_elems % 8 == 0, "mi_sumsq_bf16_multi: bad sizes");
   hipLaunchKernelGGL(mi::sumsq_multi_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, table, n_tensors,

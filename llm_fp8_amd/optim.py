@@ -108,7 +108,7 @@ class ClippedAdamW(torch.optim.Optimizer):
                     "table": torch.empty((12, len(sizes)), dtype=torch.int64, device=dev),
                     "host": [torch.empty((12, len(sizes)), dtype=torch.int64).pin_memory() for _ in range(2)], "flip": 0,
                     "uploaded": [None, None],
-                    "partials": torch.empty(len(refs), dtype=torch.float32, device=dev)}
+                    "partials": torch.empty(len(refs), dtype=torch.float64, device=dev)}
             self._plans[key] = plan
         rows = [[], [], [], [], list(sizes), [], [], [], [], [], [], []]
         for (_, p), s in zip(group_items, sinks):
@@ -197,13 +197,18 @@ class ClippedAdamW(torch.optim.Optimizer):
                 updates.append((gi, plan))
         coef_ptr = None
         if self.max_grad_norm is not None:
-            # squared norm: one launch per parameter group, one fp32 partial per 64 Ki-element chunk, fixed summation order
+            # squared norm: one launch per parameter group, one FLOAT64 partial per 64 Ki-element chunk (exact squares, fp64 sums)
             for gi, plan in plans:
                 _lib.check(lib.mi_sumsq_bf16_multi(plan["table"].data_ptr(), len(gi), plan["chunks"].data_ptr(), plan["n_chunks"],
                                                    self.CHUNK, plan["partials"].data_ptr(), st), "mi_sumsq_bf16_multi")
+            # Partials and totals stay in FLOAT64 and the norm is rounded to fp32 once: the wrappers partition the parameters
+            # differently (distributed.ShardedFP8DP: one group of row shards + the replicated rest, summed over ranks), and in
+            # fp32 the association of those sums moves the last bit of the clip coefficient -- a handful of weights then round
+            # differently and a sharded run stops being bitwise the replicated one (seen once the MLP bias fusion changed the
+            # gradients' low bits).  In float64 the order only matters below 2^-52 of the total.
             total = shard_total = None
             for gi, plan in plans:
-                t = plan["partials"].sum(dtype=torch.float32)
+                t = plan["partials"].sum(dtype=torch.float64)
                 if gi[0][0].get("sharded", False):  # row shards of ShardedFP8DP: every rank holds different rows
                     shard_total = t if shard_total is None else shard_total + t
                 else:
@@ -214,7 +219,7 @@ class ClippedAdamW(torch.optim.Optimizer):
                 if dist.is_available() and dist.is_initialized() and dist.get_world_size(grp) > 1:
                     dist.all_reduce(shard_total, op=dist.ReduceOp.SUM, group=grp)
                 total = shard_total if total is None else total + shard_total
-            total = total.sqrt()
+            total = total.sqrt().to(torch.float32)
             self.last_grad_norm = total
             coef = (self.max_grad_norm / (total + 1e-6)).clamp(max=1.0).reshape(1)  # clip_grad_norm_'s coefficient
             coef_ptr = coef.data_ptr()
