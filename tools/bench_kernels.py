@@ -266,7 +266,9 @@ def main():
         import ctypes
         from llm_fp8_amd import _lib
         cur = _lib.load()
-        base_path = os.environ.get("MI_BASE_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "libmi_fp8_r1.so"))
+        base_path = os.environ.get("MI_BASE_LIB")  # a saved build of an earlier tree (tools/bin/ is scratch: nothing is kept there)
+        if not base_path or not os.path.exists(base_path):
+            raise SystemExit("--which abbase: set MI_BASE_LIB to the libmi_fp8.so of the build to compare against")
         base = ctypes.CDLL(base_path)
         for lib_ in (base,):
             lib_.mi_gemm_fp8.argtypes = cur.mi_gemm_fp8.argtypes
