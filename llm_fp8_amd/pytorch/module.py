@@ -313,6 +313,7 @@ class _AddStatsFn(torch.autograd.Function):
     def forward(ctx, a, b, eps, bias=None):
         out, rstd = ops.add_rmsnorm_stats(a, b, eps, bias=bias)
         ctx.mark_non_differentiable(rstd)
+        ctx.set_materialize_grads(False)  # autograd otherwise zero-fills a [tokens] fp32 gradient for rstd in every backward
         return out, rstd
 
     @staticmethod
