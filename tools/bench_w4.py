@@ -78,6 +78,24 @@ def main():
                 tot[al] += res[al]
             print(f"timing {name:10s} {m}x{n}x{k}: " + "  ".join(f"a{al}: {t*1e6:7.1f} us {2.0*m*n*k/t/1e12:5.0f} TF" for al, t in res.items()), flush=True)
         print("timing total: " + "  ".join(f"a{al}: {t*1e6:8.1f} us" for al, t in tot.items()), flush=True)
+    if "cold" in args.which:  # as "timing", but every launch reads operands and writes an output no launch has touched for > 400 MB of
+        # traffic (the 256-MiB Infinity Cache holds the whole working set of a timing loop; in the training step every operand is cold)
+        algos = [int(x) for x in args.algos.split(",")]
+        for name, m, n, k in shapes:
+            per = m * k + n * k + 2 * m * n
+            nset = max(3, int(6e8 // per) + 1)
+            sets = [(rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g), torch.empty((m, n), dtype=torch.bfloat16, device=dev)) for _ in range(nset)]
+            ctr = {al: 0 for al in algos}
+            def make(al):
+                def f():
+                    a, b, out = sets[ctr[al] % nset]
+                    ctr[al] += 1
+                    ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=al)
+                return f
+            res = time_interleaved({al: make(al) for al in algos}, rounds=8, inner=nset)
+            print(f"cold {name:10s} {m}x{n}x{k} ({nset} operand sets): " + "  ".join(f"a{al}: {t*1e6:7.1f} us {2.0*m*n*k/t/1e12:5.0f} TF" for al, t in res.items()), flush=True)
+            del sets
+            torch.cuda.empty_cache()
     if "sched" in args.which:  # phase schedules of the one-tile-per-workgroup kernel (mi_gemm_w4.hip w4::sched_*): 50 + 4 S + kind
         scheds = {"S0": (6, 7, 8), "S1": (54, 55, 56), "S3": (62, 63, 64), "S4": (66, 67, 68)}
         import time
@@ -107,16 +125,25 @@ def main():
             dbg = torch.zeros(1024, dtype=torch.int64, device=dev)
             for _ in range(100):
                 ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=9)
-            rc = lib.mi_gemm_fp8(a.data_ptr(), b.data_ptr(), out.data_ptr(), one.data_ptr(), one.data_ptr(), dbg.data_ptr(), m, n, k, k, k, n, 0, 0, 0, 73, st)
-            assert rc == 0, lib.mi_last_error()
-            torch.cuda.synchronize()
-            t = dbg.cpu().numpy()
-            t = t[t > 0]
-            d = (t[1:] - t[:-1])
-            nk = k // 128
-            print(f"ktstamps {name} {m}x{n}x{k}: nk {nk}, {len(d)} K-tiles; cycles per K-tile (rows = tiles):", flush=True)
-            for ti in range(0, len(d), nk):
-                print("   " + " ".join(f"{int(x):5d}" for x in d[ti:ti + nk]), flush=True)
+            for label in ("warm", "cold"):
+                if label == "cold":  # fresh operands and output, then 1 GB of unrelated traffic: nothing of this launch is in L2 / the Infinity Cache
+                    a, b = rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)
+                    out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
+                    junk = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+                    junk.fill_(1.0)
+                    junk.mul_(2.0)
+                    del junk
+                dbg.zero_()
+                rc = lib.mi_gemm_fp8(a.data_ptr(), b.data_ptr(), out.data_ptr(), one.data_ptr(), one.data_ptr(), dbg.data_ptr(), m, n, k, k, k, n, 0, 0, 0, 73, st)
+                assert rc == 0, lib.mi_last_error()
+                torch.cuda.synchronize()
+                t = dbg.cpu().numpy()
+                t = t[t > 0]
+                d = (t[1:] - t[:-1])
+                nk = k // 128
+                print(f"ktstamps {label} {name} {m}x{n}x{k}: nk {nk}, {len(d)} K-tiles, total {int(d.sum())} cycles; cycles per K-tile (rows = tiles):", flush=True)
+                for ti in range(0, len(d), nk):
+                    print("   " + " ".join(f"{int(x):5d}" for x in d[ti:ti + nk]), flush=True)
     if "clock" in args.which:
         import time
         for name, m, n, k in shapes:
