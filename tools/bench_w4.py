@@ -79,22 +79,27 @@ def main():
                 tot[al] += res[al]
             print(f"timing {name:10s} {m}x{n}x{k}: " + "  ".join(f"a{al}: {t*1e6:7.1f} us {2.0*m*n*k/t/1e12:5.0f} TF" for al, t in res.items()), flush=True)
         print("timing total: " + "  ".join(f"a{al}: {t*1e6:8.1f} us" for al, t in tot.items()), flush=True)
-    if "cold" in args.which:  # as "timing", but every launch reads operands and writes an output no launch has touched for > 400 MB of
-        # traffic (the 256-MiB Infinity Cache holds the whole working set of a timing loop; in the training step every operand is cold)
+    if "cold" in args.which:  # every candidate twice IN ONE interleaved timing: "w" re-launches on one operand set (everything stays in
+        # the 256-MiB Infinity Cache, as in "timing"), "c" rotates over enough operand / output sets that no launch finds anything
+        # cached -- the condition of the training step for weights and saved activations.  (Timed in separate blocks the two drift
+        # apart with the clock: compare only inside one line.)
         algos = [int(x) for x in args.algos.split(",")]
         for name, m, n, k in shapes:
             per = m * k + n * k + 2 * m * n
             nset = max(3, int(6e8 // per) + 1)
             sets = [(rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g), torch.empty((m, n), dtype=torch.bfloat16, device=dev)) for _ in range(nset)]
-            ctr = {al: 0 for al in algos}
-            def make(al):
+            ctr = {}
+            def make(al, cold):
+                key = (al, cold)
+                ctr[key] = 0
                 def f():
-                    a, b, out = sets[ctr[al] % nset]
-                    ctr[al] += 1
+                    a, b, out = sets[ctr[key] % nset if cold else 0]
+                    ctr[key] += 1
                     ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=al)
                 return f
-            res = time_interleaved({al: make(al) for al in algos}, rounds=8, inner=nset)
-            print(f"cold {name:10s} {m}x{n}x{k} ({nset} operand sets): " + "  ".join(f"a{al}: {t*1e6:7.1f} us {2.0*m*n*k/t/1e12:5.0f} TF" for al, t in res.items()), flush=True)
+            res = time_interleaved({f"a{al}{'c' if cold else 'w'}": make(al, cold) for al in algos for cold in (False, True)}, rounds=8, inner=nset)
+            print(f"cold {name:10s} {m}x{n}x{k} ({nset} operand sets): " + "  ".join(
+                f"a{al}: warm {res[f'a{al}w']*1e6:7.1f} cold {res[f'a{al}c']*1e6:7.1f} us (x{res[f'a{al}c']/res[f'a{al}w']:.3f})" for al in algos), flush=True)
             del sets
             torch.cuda.empty_cache()
     if "sched" in args.which:  # phase schedules of the one-tile-per-workgroup kernel (mi_gemm_w4.hip w4::sched_*): 50 + 4 S + kind
