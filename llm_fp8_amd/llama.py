@@ -15,6 +15,7 @@ No weights, tokenizer or dataset exist offline: configs are hard-coded from the 
 """
 from __future__ import annotations
 
+import os
 import re
 from contextlib import contextmanager
 from typing import Dict, Optional
@@ -23,7 +24,8 @@ import torch
 
 from . import pytorch as te
 from .common.recipe import DelayedScaling, Format, MXFP8BlockScaling
-from .pytorch.module import residual_add_stats
+from .pytorch.fp8 import FP8GlobalStateManager
+from .pytorch.module import _can_fuse_norm, residual_add_stats
 
 LLAMA_CONFIGS: Dict[str, dict] = {
     "llama-3.2-1b": dict(hidden_size=2048, intermediate_size=8192, num_hidden_layers=16, num_attention_heads=32,
@@ -200,6 +202,53 @@ def _drop_padding_mask(module, args, kwargs):
     return args, kwargs
 
 
+def _install_final_norm_fusion(model) -> None:
+    """The HF model's final RMSNorm (`model.model.norm`, a chain of ~8 torch elementwise kernels forward and ~10 backward on the
+    [tokens, hidden] activations) in front of the lm_head: once the head is one of our FP8 Linears (accelerate's convert_model,
+    llama.convert_model), the norm is fused into the head's input cast exactly as LayerNormLinear fuses a decoder norm (K9: statistics
+    from the last decoder layer's residual add, normalisation inside mi_norm_cast, mi_rmsnorm_bwd in backward).  The module, its
+    parameter and its state-dict key stay HF's; only while `LlamaForCausalLM.forward` runs -- where the norm's output goes to
+    `lm_head` and nowhere else -- does the norm hand its weight to the head instead of running.  Anything else (the bare
+    `model.model(...)`, `output_hidden_states`, FP8 off, eval under no autocast, a head that is still nn.Linear) takes HF's forward.
+    LLM_FP8_AMD_NO_FINAL_NORM_FUSION=1 turns it off."""
+    norm = model.model.norm
+    hf_forward = norm.forward
+
+    def norm_forward(x):
+        head = getattr(norm, "_defer_head", None)
+        if (head is not None and isinstance(head, te.Linear) and x.is_cuda and x.dtype == torch.bfloat16 and norm.weight.dtype == torch.bfloat16
+                and FP8GlobalStateManager.is_fp8_enabled()
+                and _can_fuse_norm(_FinalNormView, FP8GlobalStateManager.get_fp8_recipe(), x)):
+            head._pending_norm = (norm.weight, float(norm.variance_epsilon), _handed_rstd(x), x.data_ptr(), tuple(x.shape))
+            return x
+        return hf_forward(x)
+
+    norm.forward = norm_forward
+    lm_forward = model.forward
+
+    def forward(*args, **kwargs):
+        want_hidden = kwargs.get("output_hidden_states", None)
+        if want_hidden is None:
+            want_hidden = getattr(model.config, "output_hidden_states", False)
+        keep = kwargs.get("logits_to_keep", 0)
+        if os.environ.get("LLM_FP8_AMD_NO_FINAL_NORM_FUSION") == "1" or want_hidden or not (isinstance(keep, int) and keep == 0):
+            return lm_forward(*args, **kwargs)
+        norm._defer_head = model.lm_head
+        try:
+            return lm_forward(*args, **kwargs)
+        finally:
+            norm._defer_head = None
+            if isinstance(model.lm_head, te.Linear):
+                model.lm_head._pending_norm = None
+
+    model.forward = forward
+
+
+class _FinalNormView:
+    """What module._can_fuse_norm asks of a module, for HF's LlamaRMSNorm."""
+    fused_norm, normalization, zero_centered_gamma = True, "RMSNorm", False
+
+
 class TELlamaForCausalLM:
     """te_llama.py:85-98: HF owns embeddings / final norm / lm_head / loss, our layers own the decoder."""
 
@@ -208,6 +257,7 @@ class TELlamaForCausalLM:
         with replace_decoder(te_decoder_cls=decoder_layer_cls(scenario)):
             model = LlamaForCausalLM(config)
         model.model.register_forward_pre_hook(_drop_padding_mask, with_kwargs=True)
+        _install_final_norm_fusion(model)
         return model
 
     @classmethod

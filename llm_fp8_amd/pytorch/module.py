@@ -811,15 +811,26 @@ class Linear(_FP8Module):
             is_first_microbatch = self.default_is_first_microbatch
         st = self._prepare(inp.device)
         if st is None:
+            if getattr(self, "_pending_norm", None) is not None:
+                raise RuntimeError("Linear: a deferred RMSNorm is pending but FP8 is off for this forward")
             return F.linear(inp, _master(self.weight).to(inp.dtype), None if self.bias is None else self.bias.to(inp.dtype))
         recipe, mf, mb, first = st
         # `offer_dy_handoff` (set on the lm_head by train.prepare_model): the output carries a DyHandoff through which the op
         # that consumes it directly (loss.causal_lm_loss) can deliver this layer's grad_output already quantised
         handoff = DyHandoff() if (getattr(self, "offer_dy_handoff", False) and self.training and torch.is_grad_enabled()
                                   and self.bias is None) else None
-        spec = _GemmSpec(recipe, mf, mb, 0, first, self.training, wcache=self._wcache, first_mb=is_first_microbatch,
-                         dy_handoff=handoff)
-        y = _FP8LinearFn.apply(inp, self.bias, spec, None, self.weight)
+        # `_pending_norm` (llama._DeferredFinalNorm, the causal-LM head only): the RMSNorm in front of this Linear handed its
+        # weight over instead of running, and is fused into the input cast as in LayerNormLinear (K9)
+        pn, self._pending_norm = getattr(self, "_pending_norm", None), None
+        ln_w, eps, rstd = None, 1e-5, None
+        if pn is not None:
+            ln_w, eps, rs, ptr, shape = pn
+            if inp.data_ptr() != ptr or tuple(inp.shape) != shape:
+                raise RuntimeError("Linear: a deferred RMSNorm is pending for another tensor than the one this forward received")
+            rstd = _usable_rstd(rs, inp, eps)
+        spec = _GemmSpec(recipe, mf, mb, 0, first, self.training, eps, wcache=self._wcache, first_mb=is_first_microbatch,
+                         rstd=rstd, dy_handoff=handoff)
+        y = _FP8LinearFn.apply(inp, self.bias, spec, ln_w, self.weight)
         if handoff is not None and handoff.offered():
             y._mi_dy_handoff = handoff
         return y

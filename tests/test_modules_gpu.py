@@ -921,3 +921,67 @@ def test_fp8_training_curve_tracks_hf_bf16(te, dev, scenario):
         assert fp8_curve[i] >= 0.88 * min(ref_curve[i:i + 2]), (scenario, i, fp8_curve[i], ref_curve[i])
     tail_fp8, tail_ref = sum(fp8_curve[-10:]) / 10, sum(ref_curve[-10:]) / 10
     assert abs(tail_fp8 - tail_ref) < 0.03 * tail_ref, (scenario, tail_fp8, tail_ref)
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scenario", ["default", "mxfp8"])
+def test_final_norm_fused_into_the_lm_head(te, dev, scenario, monkeypatch):
+    """llama._install_final_norm_fusion: inside LlamaForCausalLM.forward HF's final RMSNorm hands its weight to the FP8 lm_head
+    (K9 fusion in the head's input cast, statistics from the last decoder layer's residual add) instead of running its torch
+    elementwise chain.  Against the unfused route (LLM_FP8_AMD_NO_FINAL_NORM_FUSION=1): HF's norm must not run, the first loss
+    and every gradient agree within the rounding the fusion removes (HF rounds the normalised activations to bf16 twice before
+    the cast), the norm weight gets its gradient, and three optimiser steps track each other."""
+    from llm_fp8_amd import train
+    from llm_fp8_amd.pytorch.fp8 import FP8GlobalStateManager as G
+    from transformers.models.llama.modeling_llama import LlamaRMSNorm
+
+    def run(disable):
+        G.reset()
+        if disable:
+            monkeypatch.setenv("LLM_FP8_AMD_NO_FINAL_NORM_FUSION", "1")
+        else:
+            monkeypatch.delenv("LLM_FP8_AMD_NO_FINAL_NORM_FUSION", raising=False)
+        calls = {"hf": 0}
+        orig = LlamaRMSNorm.forward
+        monkeypatch.setattr(LlamaRMSNorm, "forward", lambda self, x: (calls.__setitem__("hf", calls["hf"] + 1), orig(self, x))[1])
+        cfg = train.TrainingConfig(model_name="llama-3.2-3b", batch_size=2, max_seq_length=128, mixed_precision="fp8",
+                                   fp8_scenario=scenario, use_te=True, sharding_mode="none", num_hidden_layers=2, vocab_size=2048,
+                                   learning_rate=1e-3, num_warmup_steps=0)
+        torch.manual_seed(33)
+        device = torch.device(dev)
+        model = train.prepare_model(train.create_model(cfg, device), cfg)
+        opt, sched = train.create_optimizer(model, cfg)
+        model.train()
+        gen = torch.Generator(device=device).manual_seed(9)
+        batch = train.synthetic_batch(cfg, 2048, device, gen)
+        out = model(**batch)
+        out.loss.backward()
+        first = out.loss.item()
+        grads = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
+        opt.zero_grad(set_to_none=True)
+        losses = [train.train_step(model, train.synthetic_batch(cfg, 2048, device, gen), opt, sched, cfg).item() for _ in range(3)]
+        # evaluation (FP8 off under no_grad, as accelerate's wrapper does): HF's norm runs, whatever the switch says
+        model.eval()
+        before = calls["hf"]
+        with torch.no_grad():
+            ev = model(**batch).loss.item()
+        model.train()
+        monkeypatch.setattr(LlamaRMSNorm, "forward", orig)
+        return first, grads, losses, calls["hf"], calls["hf"] - before, ev
+
+    try:
+        f1, g1, l1, n1, e1, ev1 = run(False)
+        f0, g0, l0, n0, e0, ev0 = run(True)
+    finally:
+        G.reset()
+    assert n0 == 4 + 1 and e0 == 1, (n0, e0)       # unfused: HF's final norm in each of the 4 training forwards and in the eval pass
+    assert n1 == 1 and e1 == 1, (n1, e1)           # fused: only in the eval pass
+    assert abs(f1 - f0) <= 2e-3 * abs(f0), (f1, f0)
+    assert "model.norm.weight" in g1 and g1["model.norm.weight"].abs().max() > 0
+    ds = {n: float((g1[n] - g0[n]).norm() / (g0[n].norm() + 1e-12)) for n in g0}
+    assert ds["model.norm.weight"] <= 0.02, ds
+    # MXFP8 has no scaling state: every gradient agrees to < 1 %.  Under delayed scaling the FIRST backward quantises its
+    # gradients with scale 1 (TE's initial state: most E5M2 / E4M3 values sit in the subnormal range or underflow, DESIGN.md 2),
+    # where the different bf16 roundings of the two routes flip a visible share of the quantised values
+    assert max(ds.values()) <= (0.02 if scenario == "mxfp8" else 0.4), ds
+    assert all(abs(a - b) <= 5e-3 * abs(b) for a, b in zip(l1, l0)), (l1, l0)
+    assert abs(ev1 - ev0) <= 5e-3 * abs(ev0), (ev1, ev0)

@@ -21,16 +21,19 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     torch.cuda.synchronize()
 agg = collections.Counter()
 par = collections.Counter()
+dur = collections.Counter()
 for ev in prof.events():
     ks = getattr(ev, "kernels", None) or []
     for k in ks:
         kn = k.name[:110]
-        if any(t in k.name for t in ("FillFunctor", "copyBuffer", "fillBuffer", "bfloat16_copy", "CUDAFunctor_add", "reduce_kernel")):
+        if "at::native" in k.name or "rocclr" in k.name:  # every torch-native kernel of the step
             p = ev.cpu_parent
             chain = []
             while p is not None and len(chain) < 4:
                 chain.append(p.name)
                 p = p.cpu_parent
             agg[(kn, ev.name, " < ".join(chain))] += 1
-for (kn, name, chain), n in sorted(agg.items(), key=lambda kv: -kv[1])[:50]:
-    print(n, kn, "|", name, "|", chain)
+            dur[(kn, ev.name, " < ".join(chain))] += k.duration
+for key, n in sorted(agg.items(), key=lambda kv: -dur[kv[0]])[:40]:
+    kn, name, chain = key
+    print(f"{n:3d}x {dur[key]:8.1f} us  {kn[:70]} | {name} | {chain}")
