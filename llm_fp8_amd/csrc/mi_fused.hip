@@ -378,6 +378,10 @@ __global__ __launch_bounds__(256) void rmsnorm_stats_kernel(const uint16_t* __re
 
 // y = (x * rstd[row]) * gamma[col] in fp32 -> FP8 (+ transposed copy) + amax: the normalised activation is never
 // written in bf16 (TE LayerNormLinear / LayerNormMLP do the same on the reference path, te_llama.py:45-63).
+// Persistent form (round 3), the walk of cast_amax_kernel (mi_cast.hip): every WAVE walks 64 x 64-element tiles (an 8 x 8 block per
+// lane) with stride = waves in the grid, the 8 row loads, the 8 rstd values and the gamma slice of its NEXT tile already in flight
+// while the current tile is normalised, converted and stored; two workgroups per CU (26.5 -> 24 us per 8192 x 3072 in the step's
+// conditions: profiles/r03_cast_grid_sweep.txt has the grid sweep of the sibling kernel).
 template <int FMT, bool WRITE_Y, bool WRITE_T>
 __global__ __launch_bounds__(256) void norm_cast_kernel(const uint16_t* __restrict__ x, const float* __restrict__ rstd,
                                                         const uint16_t* __restrict__ gamma, uint8_t* __restrict__ y,
@@ -385,56 +389,83 @@ __global__ __launch_bounds__(256) void norm_cast_kernel(const uint16_t* __restri
                                                         float* amax_out, int rows, int cols, int tiles_c) {
   __shared__ float s_amax[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile_r = blockIdx.x / tiles_c, tile_c = blockIdx.x % tiles_c;
-  const int r0 = tile_r * 128 + (wave >> 1) * 64 + (lane >> 3) * 8;
-  const int c0 = tile_c * 128 + (wave & 1) * 64 + (lane & 7) * 8;
+  const int ntiles = ((rows + 63) / 64) * tiles_c;  // tiles_c: 64-column tiles
+  const int stride = gridDim.x * 4;
+  const int lr = (lane >> 3) * 8, lc = (lane & 7) * 8;
   const float scale = *scale_p;
   float amax = 0.0f;
-  if ((r0 < rows) && (c0 < cols)) {
-    float g[8];
-    {
-      const v4i gv = *reinterpret_cast<const v4i*>(gamma + c0);
+  int t = blockIdx.x * 4 + wave;
+  v4i nxt[8], nxt_g;
+  v4f nxt_r[2];
+  auto load_tile = [&](int tt, v4i (&raw)[8], v4i& gv, v4f (&rs)[2]) {
+    const int r0 = (tt / tiles_c) * 64 + lr, c0 = (tt % tiles_c) * 64 + lc;
+    if (r0 < rows && c0 < cols) {  // dims are multiples of 8: blocks are all-in or all-out
+      const uint16_t* src = x + (int64_t)r0 * cols + c0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) raw[i] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(src + (int64_t)i * cols));
+      gv = *reinterpret_cast<const v4i*>(gamma + c0);
+      rs[0] = *reinterpret_cast<const v4f*>(rstd + r0);
+      rs[1] = *reinterpret_cast<const v4f*>(rstd + r0 + 4);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) raw[i] = (v4i){0, 0, 0, 0};
+      gv = (v4i){0, 0, 0, 0};
+      rs[0] = rs[1] = (v4f){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  if (t < ntiles) load_tile(t, nxt, nxt_g, nxt_r);
+  while (t < ntiles) {
+    v4i raw[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) raw[i] = nxt[i];
+    const v4i gv = nxt_g;
+    const v4f rs0 = nxt_r[0], rs1 = nxt_r[1];
+    const int tn = t + stride;
+    if (tn < ntiles) load_tile(tn, nxt, nxt_g, nxt_r);
+    const int r0 = (t / tiles_c) * 64 + lr, c0 = (t % tiles_c) * 64 + lc;
+    if ((r0 < rows) && (c0 < cols)) {
+      float g[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         g[2 * j] = __uint_as_float((u32)gv[j] << 16);
         g[2 * j + 1] = __uint_as_float((u32)gv[j] & 0xFFFF0000u);
       }
-    }
-    u32 lo[8], hi[8];
+      u32 lo[8], hi[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const v4i raw = *reinterpret_cast<const v4i*>(x + (int64_t)(r0 + i) * cols + c0);
-      const float rs = rstd[r0 + i];
-      float f[8];
+      for (int i = 0; i < 8; ++i) {
+        const float rs = i < 4 ? rs0[i] : rs1[i - 4];
+        float f[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const u32 w = (u32)raw[j];
-        f[2 * j] = (__uint_as_float(w << 16) * rs) * g[2 * j];
-        f[2 * j + 1] = (__uint_as_float(w & 0xFFFF0000u) * rs) * g[2 * j + 1];
+        for (int j = 0; j < 4; ++j) {
+          const u32 w = (u32)raw[i][j];
+          f[2 * j] = (__uint_as_float(w << 16) * rs) * g[2 * j];
+          f[2 * j + 1] = (__uint_as_float(w & 0xFFFF0000u) * rs) * g[2 * j + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, (f[j] != f[j]) ? 0.0f : fabsf(f[j]));
+        lo[i] = cvt4_fp8<FMT>(f[0] * scale, f[1] * scale, f[2] * scale, f[3] * scale);
+        hi[i] = cvt4_fp8<FMT>(f[4] * scale, f[5] * scale, f[6] * scale, f[7] * scale);
       }
+      if (WRITE_Y) {
+        uint8_t* dst = y + (int64_t)r0 * cols + c0;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, (f[j] != f[j]) ? 0.0f : fabsf(f[j]));
-      lo[i] = cvt4_fp8<FMT>(f[0] * scale, f[1] * scale, f[2] * scale, f[3] * scale);
-      hi[i] = cvt4_fp8<FMT>(f[4] * scale, f[5] * scale, f[6] * scale, f[7] * scale);
-    }
-    if (WRITE_Y) {
-      uint8_t* dst = y + (int64_t)r0 * cols + c0;
+        for (int i = 0; i < 8; ++i) mi::st8<MI_NT_Y>(dst + (int64_t)i * cols, lo[i], hi[i]);
+      }
+      if (WRITE_T) {
+        u32 a[4], b[4], c[4], d[4];
+        transpose4x4(lo[0], lo[1], lo[2], lo[3], a[0], a[1], a[2], a[3]);
+        transpose4x4(lo[4], lo[5], lo[6], lo[7], b[0], b[1], b[2], b[3]);
+        transpose4x4(hi[0], hi[1], hi[2], hi[3], c[0], c[1], c[2], c[3]);
+        transpose4x4(hi[4], hi[5], hi[6], hi[7], d[0], d[1], d[2], d[3]);
+        uint8_t* dst = yT + (int64_t)c0 * rows + r0;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) mi::st8<MI_NT_Y>(dst + (int64_t)i * cols, lo[i], hi[i]);
-    }
-    if (WRITE_T) {
-      u32 a[4], b[4], c[4], d[4];
-      transpose4x4(lo[0], lo[1], lo[2], lo[3], a[0], a[1], a[2], a[3]);
-      transpose4x4(lo[4], lo[5], lo[6], lo[7], b[0], b[1], b[2], b[3]);
-      transpose4x4(hi[0], hi[1], hi[2], hi[3], c[0], c[1], c[2], c[3]);
-      transpose4x4(hi[4], hi[5], hi[6], hi[7], d[0], d[1], d[2], d[3]);
-      uint8_t* dst = yT + (int64_t)c0 * rows + r0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        mi::st8<MI_NT_YT>(dst + (int64_t)j * rows, a[j], b[j]);
-        mi::st8<MI_NT_YT>(dst + (int64_t)(j + 4) * rows, c[j], d[j]);
+        for (int j = 0; j < 4; ++j) {
+          mi::st8<MI_NT_YT>(dst + (int64_t)j * rows, a[j], b[j]);
+          mi::st8<MI_NT_YT>(dst + (int64_t)(j + 4) * rows, c[j], d[j]);
+        }
       }
     }
+    t = tn;
   }
   if (amax_out != nullptr) {
     amax = wave_max(amax);
@@ -443,7 +474,7 @@ __global__ __launch_bounds__(256) void norm_cast_kernel(const uint16_t* __restri
     if (tid == 0) {
       float m = fmaxf(fmaxf(s_amax[0], s_amax[1]), fmaxf(s_amax[2], s_amax[3]));
       // only a workgroup that would raise the value goes to the atomic unit: same-address atomics are served one at a time and a
-      // wave cannot retire before its atomic has returned (thousands of workgroups per launch)
+      // wave cannot retire before its atomic has returned
       if (m > 0.0f && m > __builtin_nontemporal_load(amax_out)) atomicMax(reinterpret_cast<unsigned int*>(amax_out), __float_as_uint(m));
     }
   }
@@ -910,12 +941,17 @@ extern "C" int mi_norm_cast(const void* x_bf16, const float* rstd, const void* g
   MI_CHECK_ARG(y_fp8 || yT_fp8, "mi_norm_cast: at least one of y, yT must be non-null");
   MI_CHECK_ARG(rows >= 0 && cols >= 0 && rows % 8 == 0 && cols % 8 == 0, "mi_norm_cast: rows and cols must be multiples of 8");
   MI_CHECK_ARG(rows < (1LL << 31) && cols < (1LL << 31), "mi_norm_cast: shape too large");
-  MI_CHECK_ARG(((uintptr_t)x_bf16 % 16) == 0 && ((uintptr_t)gamma_bf16 % 16) == 0 && ((uintptr_t)y_fp8 % 8) == 0 &&
-                   ((uintptr_t)yT_fp8 % 8) == 0, "mi_norm_cast: misaligned pointer");
+  MI_CHECK_ARG(((uintptr_t)x_bf16 % 16) == 0 && ((uintptr_t)gamma_bf16 % 16) == 0 && ((uintptr_t)rstd % 16) == 0 &&
+                   ((uintptr_t)y_fp8 % 8) == 0 && ((uintptr_t)yT_fp8 % 8) == 0, "mi_norm_cast: misaligned pointer");
   MI_CHECK_ARG(fmt == MI_FMT_E4M3 || fmt == MI_FMT_E5M2, "mi_norm_cast: bad fmt %d", fmt);
   if (rows == 0 || cols == 0) return MI_OK;
-  const int tiles_r = (int)((rows + 127) / 128), tiles_c = (int)((cols + 127) / 128);
-  dim3 grid((unsigned)(tiles_r * tiles_c)), block(256);
+  MI_CHECK_ARG(((rows + 63) / 64) * ((cols + 63) / 64) < (1LL << 31), "mi_norm_cast: shape too large");
+  const int tiles_r = (int)((rows + 63) / 64), tiles_c = (int)((cols + 63) / 64);  // 64 x 64 tiles, one per wave and step
+  const int64_t wgs = ((int64_t)tiles_r * tiles_c + 3) / 4;
+  int ncu = 256, devid = 0;
+  if (hipGetDevice(&devid) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, devid) != hipSuccess || ncu <= 0) ncu = 256;
+  const int64_t cap = (int64_t)ncu * 2;  // two workgroups per CU, a whole multiple of the CU count (profiles/r03_cast_grid_sweep.txt)
+  dim3 grid((unsigned)(wgs < cap ? wgs : cap)), block(256);
   hipStream_t st = (hipStream_t)stream;
   const uint16_t *xp = (const uint16_t*)x_bf16, *gp = (const uint16_t*)gamma_bf16;
   uint8_t *yp = (uint8_t*)y_fp8, *tp = (uint8_t*)yT_fp8;
