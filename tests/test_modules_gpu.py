@@ -985,3 +985,37 @@ def test_final_norm_fused_into_the_lm_head(te, dev, scenario, monkeypatch):
     assert max(ds.values()) <= (0.02 if scenario == "mxfp8" else 0.4), ds
     assert all(abs(a - b) <= 5e-3 * abs(b) for a, b in zip(l1, l0)), (l1, l0)
     assert abs(ev1 - ev0) <= 5e-3 * abs(ev0), (ev1, ev0)
+
+@pytest.mark.gpu
+def test_grad_norm_does_not_depend_on_grouping_or_row_sharding(dev):
+    """optim.ClippedAdamW's squared norm: exact fp32 squares accumulated in float64 (mi_sumsq_bf16_multi), float64 totals, one
+    rounding at the end -- so the clip coefficient is the same bit pattern however the parameters are cut into groups, chunks or
+    row shards (distributed.ShardedFP8DP's groups against the replicated wrapper's: in fp32 the association moved the last bit in
+    a few percent of the steps and a handful of weights then rounded differently).  Against float64 torch on the same gradients."""
+    from llm_fp8_amd.optim import ClippedAdamW
+    torch.manual_seed(5)
+    shapes = [(2048, 1536), (4096, 1024), (777,), (1536, 2048), (33, 65)]
+    grads = [(torch.randn(s, device=dev) * (10.0 ** (i - 2))).to(torch.bfloat16) for i, s in enumerate(shapes)]
+    exact = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).to(torch.float32).item()
+
+    def norm_of(partition):
+        """partition: list of groups, a group = list of (tensor index, row slice or None)"""
+        groups = []
+        for grp in partition:
+            ps = []
+            for idx, rows in grp:
+                g = grads[idx] if rows is None else grads[idx][rows].contiguous()
+                p = torch.nn.Parameter(torch.zeros_like(g))
+                p.grad = g.clone()
+                ps.append(p)
+            groups.append({"params": ps})
+        opt = ClippedAdamW(groups, lr=0.0, max_grad_norm=1.0)
+        opt.step()
+        return opt.last_grad_norm.item()
+
+    one_group = norm_of([[(i, None) for i in range(5)]])
+    per_tensor = norm_of([[(i, None)] for i in range(5)])
+    reversed_ = norm_of([[(i, None) for i in reversed(range(5))]])
+    row_shards = norm_of([[(0, slice(0, 1024)), (1, slice(0, 2048)), (3, slice(0, 768))],
+                          [(0, slice(1024, 2048)), (1, slice(2048, 4096)), (3, slice(768, 1536))], [(2, None), (4, None)]])
+    assert one_group == per_tensor == reversed_ == row_shards == exact, (one_group, per_tensor, reversed_, row_shards, exact)
