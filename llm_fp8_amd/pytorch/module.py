@@ -603,7 +603,7 @@ class _FP8SwiGLUMLPFn(torch.autograd.Function):
         h = ops.gemm_mxfp8(x8, xs, w1_8, w1s, fmt, fmt, bias=None if b1 is None else b1.to(torch.bfloat16).contiguous())
         a8, as_, at8, ats = ops.mxfp8_swiglu_quantize(h, fmt, rowwise=True, colwise=need_w)
         w2_8, w2s, w2t8, w2ts = _FP8SwiGLUMLPFn._mx_weights(spec, 1, w2, bwd)
-        y = ops.gemm_mxfp8(a8, as_, w2_8, w2s, fmt, fmt, bias=None if b2 is None else b2.to(torch.bfloat16).contiguous())
+        y = ops.gemm_mxfp8(a8, as_, w2_8, w2s, fmt, fmt, bias=None if (b2 is None or spec.defer_bias) else b2.to(torch.bfloat16).contiguous())
         ctx.saved_fp8 = ((xt8, xts), (w1t8, w1ts), (at8, ats), (w2t8, w2ts), h if bwd else None, None)
         if spec.with_skip:
             ctx.set_materialize_grads(False)
@@ -990,7 +990,9 @@ class LayerNormMLP(_FP8Module):
         st = self._prepare(inp.device)
         if (st is not None and self.activation == "swiglu" and self.fused_swiglu and _can_fuse_norm(self, st[0], inp)):
             recipe, mf, mb, first = st  # K9 + K10: norm -> cast, fc1, SwiGLU -> cast, fc2 in one autograd node
-            defer = bool(_defer_bias and _with_skip and _FUSE_MLP_BIAS and self.fc2_bias is not None and not recipe.mxfp8())
+            # (the residual add that takes the deferred fc2 bias is recipe-independent: MXFP8 defers too; the fc1 bias stays in the
+            # MXFP8 GEMM's epilogue, its quantising SwiGLU kernels have no bias form)
+            defer = bool(_defer_bias and _with_skip and _FUSE_MLP_BIAS and self.fc2_bias is not None)
             res = _FP8SwiGLUMLPFn.apply(inp, self.fc1_weight, self.fc1_bias, self.fc2_weight, self.fc2_bias,
                                         _GemmSpec(recipe, mf, mb, 0, first, self.training, self.eps, self._wcache,
                                                   is_first_microbatch, with_skip=_with_skip, rstd=_usable_rstd(_rstd, inp, self.eps),
