@@ -1406,10 +1406,18 @@ static int launch_p8(const uint8_t* a, const uint8_t* b, uint16_t* D, const floa
         MI_P8_CFG(false, false, 13)
       } else if (algo == 24) {  // A/B baseline: half-line epilogue stores (16 rows x 64 B per instruction)
         MI_P8_CFG(false, false, 11)
-      } else if (algo == 18) {  // block scales staged into LDS but not read (unit scales): wrong results
-        MI_P8_CFG(true, false, 5)
-      } else if (algo == 19) {  // block scales staged and read, MFMAs still get unit scales: wrong results
-        MI_P8_CFG(true, false, 6)
+      } else if (algo == 18 || algo == 19) {
+        // (lab) the MX scale path without its effect: they read the block scales, so they exist for mi_gemm_mxfp8 only -- through
+        // mi_gemm_fp8 the scale pointers are null and the kernel faults (it did once, from a sweep script)
+        if (SA == nullptr || SB == nullptr) {
+          set_error("mi_gemm: diagnostic algo %d reads MXFP8 block scales: call it through mi_gemm_mxfp8", algo);
+          return MI_ERR_ARG;
+        }
+        if (algo == 18) {  // block scales staged into LDS but not read (unit scales): wrong results
+          MI_P8_CFG(true, false, 5)
+        } else {  // block scales staged and read, MFMAs still get unit scales: wrong results
+          MI_P8_CFG(true, false, 6)
+        }
       } else {
         set_error("mi_gemm: unknown diagnostic algo %d", algo);
         return MI_ERR_ARG;

@@ -21,7 +21,7 @@ def main():
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)
     one = torch.ones(1, device=dev)
-    m, n, k = 8192, 16384, 3072
+    m, n, k = [int(x) for x in os.environ.get("SUSTAINED_SHAPE", "8192,16384,3072").split(",")]
     data = {
         "random bytes": (rand_fp8((m, k), dev, g), rand_fp8((n, k), dev, g)),
         "gaussian, quantised as in training (amax -> 448)": tuple(
@@ -31,11 +31,18 @@ def main():
     }
     out = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
     variants = [("eight-wave persistent (algo 4)", 4), ("four-wave persistent (algo 9)", 9), ("algo 4, no stores (15)", 15),
-                ("algo 4, every tile reads panel (0,0): no fabric traffic (20)", 20), ("algo 9, no epilogue (12)", 12)]
+                ("algo 4, every tile reads panel (0,0): no fabric traffic (20)", 20), ("algo 9, no epilogue (12)", 12),
+                ("algo 4 with plain (write-back) stores (17)", 17), ("algo 4 with nt stores (25)", 25), ("algo 4 with sc1 nt stores (26)", 26),
+                ("algo 9 with plain stores (70)", 70), ("algo 9 with nt stores (71)", 71), ("algo 9 with sc1 nt stores (72)", 72)]
     flop = 2.0 * m * n * k
+    only = [int(x) for x in os.environ.get("SUSTAINED_ALGOS", "").split(",") if x]
     for dname, (a, b) in data.items():
+        if only and dname.startswith("zeros"):
+            continue
         for vname, algo in variants:
-            if dname != "random bytes" and algo not in (4, 9):
+            if only and algo not in only:
+                continue
+            if not only and (algo in (17, 25, 26, 70, 71, 72) or (dname != "random bytes" and algo not in (4, 9))):
                 continue
             def launch():
                 ops.gemm_fp8(a, b, one, one, 0, 0, out=out, algo=algo)
