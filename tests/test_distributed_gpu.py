@@ -7,9 +7,19 @@ import subprocess
 import sys
 
 import pytest
+import socket
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port() -> str:
+    """A rendezvous port nobody holds right now: consecutive parametrised cases otherwise re-bind one fixed port seconds after the
+    previous torchrun closed it (one run of the sharded cases once sat in rendezvous until the outer timeout)."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
 
 
 @pytest.mark.parametrize("mode,scenario", [("fsdp_full", "default"), ("ddp", "default"), ("fsdp_full", "mxfp8"),
@@ -18,7 +28,7 @@ def test_train_harness_under_wrappers_world1(dev, mode, scenario):
     # replicated: the gradient-arena wrapper with its RCCL all-reduces forced on at world size 1 (stream hand-over, hooks)
     env = dict(os.environ, LLM_FP8_AMD_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", LLM_FP8_AMD_FORCE_COLLECTIVES="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29531", "-m", "llm_fp8_amd.train", "--model_name", "llama-3.2-1b", "--num_hidden_layers", "2",
+           "--master-port", _free_port(), "-m", "llm_fp8_amd.train", "--model_name", "llama-3.2-1b", "--num_hidden_layers", "2",
            "--vocab_size", "4096", "--batch_size", "4", "--max_seq_length", "128", "--mixed_precision", "fp8", "--use_te",
            "--fp8_scenario", scenario, "--sharding_mode", mode, "--num_steps", "4", "--learning_rate", "1e-3",
            "--num_warmup_steps", "0", "--repeat_batch"]
@@ -40,7 +50,7 @@ def test_fsdp_full_shard_matches_the_unwrapped_run(dev, world, scenario):
     else:
         env.update(LLM_FP8_AMD_DIST_BACKEND="gloo", LLM_FP8_AMD_SHARE_DEVICE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", "29537", os.path.join(ROOT, "tests", "fsdp_equiv_worker.py"), scenario]
+           "--master-port", _free_port(), os.path.join(ROOT, "tests", "fsdp_equiv_worker.py"), scenario]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     if world == 2 and r.returncode != 0 and ("reduce_scatter" in r.stderr or "not supported" in r.stderr or "NotImplementedError" in r.stderr):
         pytest.skip("this torch build's gloo backend lacks a collective FSDP needs on CUDA tensors: " + r.stderr[-300:])
@@ -72,7 +82,7 @@ def test_sharded_fp8_dp_matches_the_replicated_run(dev, world, scenario):
     else:
         env.update(LLM_FP8_AMD_DIST_BACKEND="gloo", LLM_FP8_AMD_SHARE_DEVICE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", "29539", os.path.join(ROOT, "tests", "fsdp_fp8_worker.py"), scenario]
+           "--master-port", _free_port(), os.path.join(ROOT, "tests", "fsdp_fp8_worker.py"), scenario]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     outs = sorted((json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")), key=lambda o: o["rank"])
@@ -99,7 +109,7 @@ def test_two_ranks_share_the_gpu_gradient_arena(dev, scenario):
     reduced gradient is exactly the bf16 mean of the two ranks' local gradients."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LLM_FP8_AMD_DIST_BACKEND="gloo", LLM_FP8_AMD_SHARE_DEVICE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "tests", "dp_two_rank_worker.py"), scenario]
+           "--master-port", _free_port(), os.path.join(ROOT, "tests", "dp_two_rank_worker.py"), scenario]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     outs = sorted((json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")), key=lambda o: o["rank"])
@@ -122,7 +132,7 @@ def test_bench_two_rank_path_on_one_gpu(dev):
     resolved parallelism mode), on a 2-layer model."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LLM_FP8_AMD_DIST_BACKEND="gloo", LLM_FP8_AMD_SHARE_DEVICE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29535", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--layers", "2",
+           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--layers", "2",
            "--batch", "4", "--no-cpu-baseline"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
