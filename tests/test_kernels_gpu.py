@@ -40,7 +40,7 @@ def test_cast_exhaustive_all_bf16(ops, dev, fmt, scale):
     assert amax.item() == a == np.inf
 
 
-@pytest.mark.parametrize("shape", [(8, 8), (16, 136), (136, 72), (1000, 264), (1024, 3072)])
+@pytest.mark.parametrize("shape", [(8, 8), (16, 136), (136, 72), (1000, 264), (1024, 3072), (4104, 3080)])  # the last: > 1 tile per wave of the persistent walk, ragged both ways
 @pytest.mark.parametrize("fmt", [O.E4M3, O.E5M2])
 def test_cast_ragged_shapes_and_amax(ops, dev, shape, fmt):
     g = torch.Generator().manual_seed(shape[0] * 7 + shape[1])
@@ -580,7 +580,7 @@ def test_add_rmsnorm_stats_matches_add_then_stats(ops, dev, shape):
     np.testing.assert_allclose(rstd.cpu().numpy(), ops.rmsnorm_stats(want, 1e-5).cpu().numpy(), rtol=1e-6)
 
 
-@pytest.mark.parametrize("shape", [(8, 512), (136, 1024), (1024, 3072), (64, 4096)])
+@pytest.mark.parametrize("shape", [(8, 512), (136, 1024), (1024, 3072), (64, 4096), (4104, 3072)])  # the last: > 1 tile per wave of the persistent walk
 def test_rmsnorm_cast_and_backward_vs_oracle(ops, dev, shape):
     R, C = shape
     g = torch.Generator().manual_seed(R + C)
