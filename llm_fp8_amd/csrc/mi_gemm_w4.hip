@@ -712,8 +712,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p(const std::conditional_t<MODE
   using p1_t = std::integral_constant<int, 1>;
   using p2_t = std::integral_constant<int, 2>;
   using p3_t = std::integral_constant<int, 3>;
-  auto ktile = [&](auto mode_c, auto par_c, const epi_t& e, int rb_cur) __attribute__((always_inline)) {
+  // simple_c: this K-tile's stage cursor stays inside its tile (every MID K-tile but the last pair's): three scalar adds instead of
+  // the ~20 selects + the tile-table lookup of the general advance -- issue slots of the one wave that also issues the MFMAs
+  auto ktile = [&](auto mode_c, auto par_c, const epi_t& e, int rb_cur, auto simple_c) __attribute__((always_inline)) {
     constexpr int par = decltype(par_c)::value;
+    constexpr bool SIMPLE = decltype(simple_c)::value && !GROUPED;
     uint8_t* const cur = par ? buf1 : buf0;
     if (ABL == 7) {
       if (bid == 0 && wave == 0 && stamp_idx < 1024) {
@@ -730,7 +733,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p(const std::conditional_t<MODE
           [&](int n) __attribute__((always_inline)) { read_part(aA, fa_lo[par ^ 1], fa_hi[par ^ 1], 0, n); }, e, rb_cur);
     phase(mode_c, p3_t{}, aB, b0[par], acc[1][0], [&](int p) __attribute__((always_inline)) { stage_a(1, c2, cur, p); },
           [&](int n) __attribute__((always_inline)) { read_part(b0[par ^ 1], fb_lo[par ^ 1], fb_hi[par ^ 1], 0, n); }, e, rb_cur);
-    advance(c2);
+    if constexpr (SIMPLE) {
+      c2.step += 1;
+      c2.kt += 1;
+      c2.kb += BK;
+    } else {
+      advance(c2);
+    }
   };
 
   if (my_tiles <= 0) return;
@@ -798,14 +807,22 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p(const std::conditional_t<MODE
     int nk_t;
     if constexpr (GROUPED) nk_t = ka.p[p_].nk;
     else nk_t = ka.K / BK;
-    ktile(first_t{}, par0_t{}, ep_prev, rb_cur);
-    ktile(second_t{}, par1_t{}, ep_prev, rb_cur);
-    ktile(third_t{}, par0_t{}, ep_cur, rb_cur);
-    for (int pair = 2; pair < nk_t / 2; ++pair) {
-      ktile(mid_t{}, par1_t{}, ep_cur, rb_cur);
-      ktile(mid_t{}, par0_t{}, ep_cur, rb_cur);
+    using full_t = std::false_type;
+    using simple_t = std::true_type;
+    ktile(first_t{}, par0_t{}, ep_prev, rb_cur, full_t{});
+    ktile(second_t{}, par1_t{}, ep_prev, rb_cur, full_t{});
+    ktile(third_t{}, par0_t{}, ep_cur, rb_cur, full_t{});
+    // MID K-tiles j = 3 .. nk - 2; the stage cursor (two K-tiles ahead, advanced at the end of a K-tile) leaves the tile in j = nk - 3
+    const int npair = nk_t / 2;
+    for (int pair = 2; pair < npair - 1; ++pair) {
+      ktile(mid_t{}, par1_t{}, ep_cur, rb_cur, simple_t{});
+      ktile(mid_t{}, par0_t{}, ep_cur, rb_cur, simple_t{});
     }
-    ktile(last_t{}, par1_t{}, ep_cur, rb_cur);
+    if (npair > 2) {
+      ktile(mid_t{}, par1_t{}, ep_cur, rb_cur, full_t{});
+      ktile(mid_t{}, par0_t{}, ep_cur, rb_cur, full_t{});
+    }
+    ktile(last_t{}, par1_t{}, ep_cur, rb_cur, full_t{});
     ep_prev = ep_cur;
     steps_done += nk_t;
   }

@@ -34,7 +34,7 @@ def ensure_gemm_workspace(device: torch.device) -> None:
 
 
 def default_gemm_algo() -> int:
-    """0 (auto: persistent kernel) on a single GPU.  Under torch.distributed with more than one rank 5 = the same kernel
+    """47 (auto: four-wave persistent kernel where it applies, else the eight-wave one) on a single GPU.  Under torch.distributed with more than one rank 5 = the same kernel
     launched with one workgroup per tile: RCCL's collectives overlap the GEMMs under FSDP / DDP and hold some CUs; a
     persistent grid with one workgroup per CU and a static tile list would wait for those CUs, while a plain grid is simply
     scheduled onto the CUs that are free (measured on a free chip: 5 is ~2 % slower than 4, the old 8-phase kernel 3 ~9 %).
@@ -45,11 +45,11 @@ def default_gemm_algo() -> int:
     d = torch.distributed
     if d.is_available() and d.is_initialized() and d.get_world_size() > 1:
         return 5
-    # LLM_FP8_AMD_GEMM_W4=1: auto with the persistent four-wave kernel (mi_gemm_w4.hip) on the shapes it takes.  Off by default: it is
-    # 2-5 % faster per launch on the no-bias 256-multiple shapes but those are ~13 % of the step's GEMM time (the biased fc1 / fc2
-    # forward and the grouped backward launches stay on the eight-wave kernel), and the same-box A/B of the whole step reads the
-    # same tokens/s either way (profiles/r03_instep_w4_ab.txt)
-    return 47 if os.environ.get("LLM_FP8_AMD_GEMM_W4", "0") == "1" else 0
+    # 47 = auto with the persistent four-wave kernel (mi_gemm_w4.hip) on the shapes it takes (256-multiples where the eight-wave kernel's
+    # own choice is 256 x 256 tiles), the eight-wave kernel elsewhere; bit-identical outputs.  Default since the cheap mid-tile cursor
+    # advance and the scalar alpha multiplies (end of round 3): -2.5 % over the twelve 3B decoder shapes in a timing loop, GEMM rate
+    # of the step 0.5310 against 0.5285 on one box (profiles/r03_instep_w4_ab.txt).  LLM_FP8_AMD_GEMM_W4=0: eight-wave kernel only.
+    return 47 if os.environ.get("LLM_FP8_AMD_GEMM_W4", "1") != "0" else 0
 
 
 def _stream() -> int:
