@@ -716,7 +716,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p(const std::conditional_t<MODE
   // the ~20 selects + the tile-table lookup of the general advance -- issue slots of the one wave that also issues the MFMAs
   auto ktile = [&](auto mode_c, auto par_c, const epi_t& e, int rb_cur, auto simple_c) __attribute__((always_inline)) {
     constexpr int par = decltype(par_c)::value;
-    constexpr bool SIMPLE = decltype(simple_c)::value && !GROUPED;
+    constexpr bool SIMPLE = decltype(simple_c)::value;  // (grouped form too: its general advance is a branch per K-tile)
     uint8_t* const cur = par ? buf1 : buf0;
     if (ABL == 7) {
       if (bid == 0 && wave == 0 && stamp_idx < 1024) {

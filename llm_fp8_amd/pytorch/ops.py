@@ -436,7 +436,7 @@ def grouped_gemm_choice(problems, fmt_a: int, fmt_b: int) -> int:
     return grouped_gemm_autotune(problems, fmt_a, fmt_b)
 
 
-def grouped_gemm_autotune(problems, fmt_a: int, fmt_b: int, iters: int = 3) -> int:
+def grouped_gemm_autotune(problems, fmt_a: int, fmt_b: int, iters: int = 5) -> int:
     """Measured choice for a recurring group of GEMMs (a Linear's dgrad + wgrad): -1 = separate launches, 0-3 = one grouped launch
     with that tile shape, 4 = one grouped launch of 256 x 256 tiles on the four-wave kernel.  Timed once per (shapes, formats) on the operands at hand but into SCRATCH outputs (the live dX buffer and
     gradient-arena slot are not touched), and cached.  The model (grouped_gemm_plan) ranks the same candidates from counts alone;
@@ -458,7 +458,7 @@ def grouped_gemm_autotune(problems, fmt_a: int, fmt_b: int, iters: int = 3) -> i
     def run(c):
         if c == -1:
             for a8, b8, sa, sb, out in problems:
-                gemm_fp8(a8, b8, sa, sb, fmt_a, fmt_b, out=out, algo=4)
+                gemm_fp8(a8, b8, sa, sb, fmt_a, fmt_b, out=out)  # the default algo: what two separate launches would really run
         else:
             gemm_fp8_grouped(problems, fmt_a, fmt_b, tile_cfg=c)
 
@@ -491,6 +491,10 @@ def grouped_gemm_autotune(problems, fmt_a: int, fmt_b: int, iters: int = 3) -> i
             t = total[c]
             if best_t is None or t < best_t * (0.98 if best == -1 else 1.0):  # a grouped launch must win by 2 % over separate ones
                 best, best_t = c, t
+        # the four-wave grouped form is 3-5 % ahead of the eight-wave one on every 3B site in a quiet timing loop
+        # (profiles/r03_grouped_w4_ab.txt); inside a first backward the five rounds above still carry ~1 % of noise: it takes ties
+        if 4 in total and best not in (-1, 4) and total[4] <= 1.01 * best_t:
+            best, best_t = 4, total[4]
     finally:
         KernelTimer.active = saved
     _GROUP_TUNED[key] = best
