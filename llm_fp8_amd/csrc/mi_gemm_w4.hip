@@ -603,7 +603,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p(const std::conditional_t<MODE
       // the AGPR -> VGPR copy of an asm output is placed at its DEFINITION (right behind the tile's last MFMA), i.e. a whole
       // quadrant would sit in 64 VGPRs until its chunks come up; passing the tile through an empty asm here pins the copy here
       asm volatile("" : "+a"(acc[a][b][i][sub]));
-      v4f v = acc[a][b][i][sub] * e.alpha;
+      // four SCALAR multiplies: as a <4 x float> product the back end emits two v_pk_mul_f32, 12 cycles each on this wave's issue port
+      // against 4.3 for a v_mul_f32 (tools/probe_mfma_shadow.hip); the empty asm keeps the legaliser from re-pairing them
+      const v4f t = acc[a][b][i][sub];
+      float m0 = t[0] * e.alpha, m1 = t[1] * e.alpha, m2 = t[2] * e.alpha, m3 = t[3] * e.alpha;
+      asm volatile("" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3));
+      v4f v = {m0, m1, m2, m3};
       if constexpr (BIAS) {
         v[0] += __uint_as_float(bias_w[b][sub].x << 16);
         v[1] += __uint_as_float(bias_w[b][sub].x & 0xFFFF0000u);
