@@ -447,8 +447,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p(const std::conditional_t<MODE
 
   uint8_t* const buf0 = lds;
   uint8_t* const buf1 = lds + kBufBytes;
-  auto dma = [&](rsrc_t rs, uint8_t* dst, int voff, int soff) __attribute__((always_inline)) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(dst), 16, voff, soff, 0, 0);
+  // The four pieces p = 0..3 of a stage group land 1 KiB apart in LDS: ONE M0 value (the group's base) + the instruction's immediate
+  // offset p * 1024 instead of an s_mov m0 (and its hazard s_nop) in front of every DMA -- 12 scalar instructions of the MFMA wave's own
+  // issue port per K-tile.  The immediate shifts the GLOBAL address as well, so the scalar offset carries - p * 1024 (never below zero:
+  // it holds at least p * 8 * ld with ld >= 512); the descriptors are 4 KiB longer than the operands because the range check adds
+  // the immediate to the per-lane offset (the scalar offset is outside the check anyway).
+  auto dma = [&](rsrc_t rs, uint8_t* dst_base, int voff, int soff, auto p_c) __attribute__((always_inline)) {
+    constexpr int IMM = decltype(p_c)::value * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(dst_base), 16, voff, soff - IMM, IMM, 0);
   };
   // stage cursor: wave-uniform (problem, tile origin, K offset) of step s + 2, clamped to the last step.  a_v / b_v: per-lane
   // byte offset row * ld + chunk of the wave's first piece (they depend on the problem's leading dimensions)
@@ -464,8 +470,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p(const std::conditional_t<MODE
       c.nk = P.nk;
       c.lda = P.lda;
       c.ldb = P.ldb;
-      c.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A, 0, P.a_bytes, 0x00020000);
-      c.rsB = __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, P.b_bytes, 0x00020000);
+      c.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A, 0, (int)((unsigned)P.a_bytes + 4096u), 0x00020000);
+      c.rsB = __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, (int)((unsigned)P.b_bytes + 4096u), 0x00020000);
       int ln;
       asm volatile("v_mov_b32 %0, %1" : "=v"(ln) : "v"(lane));  // (not hoisted: nothing of this stays live across the K loop)
       const int lr = ln >> 3, chunk = ((ln & 7) ^ swz_f(lr)) * 16;
@@ -503,11 +509,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p(const std::conditional_t<MODE
       enter_tile(c, c.ti);
     }
   };
-  auto stage_a = [&](int h, const cursor_t& c, uint8_t* buf, int p) __attribute__((always_inline)) {
-    dma(c.rsA, buf + (h ? kOffA1 : kOffA0) + (wave * 4 + p) * 1024, c.a_v, c.oa + c.kb + (h * 64 + p * 8) * c.lda);
+  auto stage_a = [&](int h, const cursor_t& c, uint8_t* buf, auto p_c) __attribute__((always_inline)) {
+    constexpr int p = decltype(p_c)::value;
+    dma(c.rsA, buf + (h ? kOffA1 : kOffA0) + wave * 4096, c.a_v, c.oa + c.kb + (h * 64 + p * 8) * c.lda, p_c);
   };
-  auto stage_b = [&](int h, const cursor_t& c, uint8_t* buf, int p) __attribute__((always_inline)) {
-    dma(c.rsB, buf + (h ? kOffB1 : kOffB0) + (wave * 4 + p) * 1024, c.b_v, c.ob + c.kb + (h * 64 + p * 8) * c.ldb);
+  auto stage_b = [&](int h, const cursor_t& c, uint8_t* buf, auto p_c) __attribute__((always_inline)) {
+    constexpr int p = decltype(p_c)::value;
+    dma(c.rsB, buf + (h ? kOffB1 : kOffB0) + wave * 4096, c.b_v, c.ob + c.kb + (h * 64 + p * 8) * c.ldb, p_c);
   };
 
   int fa_lo[2], fa_hi[2], fb_lo[2], fb_hi[2];
@@ -703,9 +711,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p(const std::conditional_t<MODE
         __builtin_amdgcn_s_barrier();
         if constexpr (BIAS && MODE_ == w4::SECOND && P == 0) load_bias(rb_cur);
       }
-#pragma unroll
-      for (int p = 0; p < 4; ++p)
-        if (k == w4::sched_dm(S, p)) stage(p);
+      static_for<4>([&](auto p_c) __attribute__((always_inline)) {
+        if constexpr (k == w4::sched_dm(S, decltype(p_c)::value)) stage(p_c);
+      });
 #pragma unroll
       for (int n = 0; n < 8; ++n)
         if (k == w4::sched_rd(S, n)) read(n);
@@ -730,13 +738,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p(const std::conditional_t<MODE
       }
       ++stamp_idx;
     }
-    phase(mode_c, p0_t{}, aA, b0[par], acc[0][0], [&](int p) __attribute__((always_inline)) { stage_a(0, c2, cur, p); },
+    phase(mode_c, p0_t{}, aA, b0[par], acc[0][0], [&](auto p) __attribute__((always_inline)) { stage_a(0, c2, cur, p); },
           [&](int n) __attribute__((always_inline)) { read_part(b1, fb_lo[par], fb_hi[par], 1, n); }, e, rb_cur);
-    phase(mode_c, p1_t{}, aA, b1, acc[0][1], [&](int p) __attribute__((always_inline)) { stage_b(0, c2, cur, p); },
+    phase(mode_c, p1_t{}, aA, b1, acc[0][1], [&](auto p) __attribute__((always_inline)) { stage_b(0, c2, cur, p); },
           [&](int n) __attribute__((always_inline)) { read_part(aB, fa_lo[par], fa_hi[par], 1, n); }, e, rb_cur);
-    phase(mode_c, p2_t{}, aB, b1, acc[1][1], [&](int p) __attribute__((always_inline)) { stage_b(1, c2, cur, p); },
+    phase(mode_c, p2_t{}, aB, b1, acc[1][1], [&](auto p) __attribute__((always_inline)) { stage_b(1, c2, cur, p); },
           [&](int n) __attribute__((always_inline)) { read_part(aA, fa_lo[par ^ 1], fa_hi[par ^ 1], 0, n); }, e, rb_cur);
-    phase(mode_c, p3_t{}, aB, b0[par], acc[1][0], [&](int p) __attribute__((always_inline)) { stage_a(1, c2, cur, p); },
+    phase(mode_c, p3_t{}, aB, b0[par], acc[1][0], [&](auto p) __attribute__((always_inline)) { stage_a(1, c2, cur, p); },
           [&](int n) __attribute__((always_inline)) { read_part(b0[par ^ 1], fb_lo[par ^ 1], fb_hi[par ^ 1], 0, n); }, e, rb_cur);
     if constexpr (SIMPLE) {
       c2.step += 1;
@@ -754,8 +762,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p(const std::conditional_t<MODE
     c2.nk = ka.K / BK;
     c2.lda = ka.lda;
     c2.ldb = ka.ldb;
-    c2.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)ka.A, 0, ka.a_bytes, 0x00020000);
-    c2.rsB = __builtin_amdgcn_make_buffer_rsrc((void*)ka.B, 0, ka.b_bytes, 0x00020000);
+    c2.rsA = __builtin_amdgcn_make_buffer_rsrc((void*)ka.A, 0, (int)((unsigned)ka.a_bytes + 4096u), 0x00020000);
+    c2.rsB = __builtin_amdgcn_make_buffer_rsrc((void*)ka.B, 0, (int)((unsigned)ka.b_bytes + 4096u), 0x00020000);
     const int lr = lane >> 3, chunk = ((lane & 7) ^ swz_f(lr)) * 16;
     const int row = (wave >> 1) * 128 + (wave & 1) * 32 + lr;
     c2.a_v = row * ka.lda + chunk;
@@ -764,12 +772,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4p(const std::conditional_t<MODE
   }
   enter_tile(c2, 0);
   auto stage4a = [&](int h, uint8_t* buf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) stage_a(h, c2, buf, p);
+    static_for<4>([&](auto p_c) __attribute__((always_inline)) { stage_a(h, c2, buf, p_c); });
   };
   auto stage4b = [&](int h, uint8_t* buf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) stage_b(h, c2, buf, p);
+    static_for<4>([&](auto p_c) __attribute__((always_inline)) { stage_b(h, c2, buf, p_c); });
   };
   stage4a(0, buf0);
   stage4b(0, buf0);
